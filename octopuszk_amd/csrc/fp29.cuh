@@ -1,0 +1,317 @@
+// 254-bit prime-field arithmetic for gfx950 in 9 x 29-bit unsaturated limbs,
+// Montgomery radix R = 2^261, one field element per lane (registers only).
+//
+// Why this shape (measured on MI355X, profiles/r01_ubench.txt): v_mad_u64_u32 issues
+// at ~5 cycles/wave but has no carry-in, and VALU carry chains through VCC/SGPRs cost
+// ~4.4 cycles per link on gfx950.  With 29-bit limbs a whole product column
+// (<= 9 a*b + 9 m*p terms) fits a 64-bit accumulator, so a Montgomery multiplication
+// is 171 plain `(u64)a*b + acc` MADs with no carry handling (~915 cycles/wave,
+// 172 G mulmod/s chip-wide) and add/sub never touch carry flags.
+//
+// Replaces the role of CGBN 512-bit `mul` + `rem` in the reference
+// (algebra_msm_VariableBaseMSM.cu:316-317 pattern) and
+// of java.math.BigInteger in algebra/fields/Fp.java:38-92.
+//
+// Value bounds are tracked at COMPILE TIME: Fe<P,B> holds an integer < B*p/16 whose
+// limbs 0..7 are < 2^29 ("normalised"); every operation static_asserts its
+// precondition and returns the tightest bound it can prove, so a formula whose
+// lazy reductions are insufficient does not compile.
+#pragma once
+#include "consts_gen.h"
+#include <type_traits>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define OZK_HD __host__ __device__ __forceinline__
+#else
+#define OZK_HD inline
+#endif
+
+namespace ozk {
+
+constexpr int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+// 2^261 / p > 169 for both BN254 primes (p < 2^253.6): out/p < 1 + (A/p)(B/p)/169.
+constexpr int MONT_SLACK = 169;
+constexpr int FE_BMAX = 16 * FE_MAXK;
+
+template <class P, int B>
+struct Fe {
+  static_assert(B >= 1 && B <= FE_BMAX, "bound out of range");
+  u32 l[9];
+  OZK_HD Fe() {}
+  // widening (never narrowing) conversion between bounds
+  template <int B2, class = std::enable_if_t<(B2 <= B)>>
+  OZK_HD Fe(const Fe<P, B2>& o) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) l[i] = o.l[i];
+  }
+};
+
+template <class P, int B>
+OZK_HD Fe<P, B> fe_const(const u32 (&c)[9]) {
+  Fe<P, B> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = c[i];
+  return r;
+}
+template <class P>
+OZK_HD Fe<P, 16> fe_one() { return fe_const<P, 16>(P::ONE); }
+template <class P>
+OZK_HD Fe<P, 1> fe_zero() {
+  Fe<P, 1> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = 0;
+  return r;
+}
+
+// zero / one of the same field as the argument (lets ec.cuh stay generic over Fq / Fq2)
+template <class P, int B>
+OZK_HD Fe<P, 1> el_zero(const Fe<P, B>&) { return fe_zero<P>(); }
+template <class P, int B>
+OZK_HD Fe<P, 16> el_one(const Fe<P, B>&) { return fe_one<P>(); }
+
+OZK_HD u64 mad64(u32 a, u32 b, u64 c) { return (u64)a * b + c; }
+
+// carry-propagate limbs 0..7 down to < 2^29 (limb 8 keeps the rest)
+template <class P, int B>
+OZK_HD void fe_carry(Fe<P, B>& a) {
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    a.l[i + 1] += a.l[i] >> FE_W;
+    a.l[i] &= FE_MASK;
+  }
+}
+
+// ---------------------------------------------------------------- mul / sqr
+template <class P, int B1, int B2>
+OZK_HD auto mul(const Fe<P, B1>& a, const Fe<P, B2>& b) {
+  static_assert((long long)B1 * B2 <= (long long)MONT_SLACK * 256, "Montgomery input bounds too large");
+  constexpr int BO = 16 + ceil_div((long long)B1 * B2, 16 * MONT_SLACK);
+  Fe<P, BO> r;
+  u32 m[9];
+  u64 acc = 0;
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+#pragma unroll
+    for (int i = 0; i <= k; i++) acc = mad64(a.l[i], b.l[k - i], acc);
+#pragma unroll
+    for (int i = 0; i < k; i++) acc = mad64(m[i], P::P[k - i], acc);
+    m[k] = ((u32)acc * P::PINV) & FE_MASK;
+    acc = mad64(m[k], P::P[0], acc);
+    acc >>= FE_W;
+  }
+#pragma unroll
+  for (int k = 9; k < 17; k++) {
+#pragma unroll
+    for (int i = k - 8; i < 9; i++) acc = mad64(a.l[i], b.l[k - i], acc);
+#pragma unroll
+    for (int i = k - 8; i < 9; i++) acc = mad64(m[i], P::P[k - i], acc);
+    r.l[k - 9] = (u32)acc & FE_MASK;
+    acc >>= FE_W;
+  }
+  r.l[8] = (u32)acc;
+  return r;
+}
+
+template <class P, int B1>
+OZK_HD auto sqr(const Fe<P, B1>& a) {
+  static_assert((long long)B1 * B1 <= (long long)MONT_SLACK * 256, "Montgomery input bounds too large");
+  constexpr int BO = 16 + ceil_div((long long)B1 * B1, 16 * MONT_SLACK);
+  Fe<P, BO> r;
+  u32 m[9], a2[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) a2[i] = a.l[i] << 1;
+  u64 acc = 0;
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+#pragma unroll
+    for (int i = 0; 2 * i < k; i++) acc = mad64(a2[i], a.l[k - i], acc);
+    if (k % 2 == 0) acc = mad64(a.l[k / 2], a.l[k / 2], acc);
+#pragma unroll
+    for (int i = 0; i < k; i++) acc = mad64(m[i], P::P[k - i], acc);
+    m[k] = ((u32)acc * P::PINV) & FE_MASK;
+    acc = mad64(m[k], P::P[0], acc);
+    acc >>= FE_W;
+  }
+#pragma unroll
+  for (int k = 9; k < 17; k++) {
+#pragma unroll
+    for (int i = k - 8; 2 * i < k; i++) acc = mad64(a2[i], a.l[k - i], acc);
+    if (k % 2 == 0) acc = mad64(a.l[k / 2], a.l[k / 2], acc);
+#pragma unroll
+    for (int i = k - 8; i < 9; i++) acc = mad64(m[i], P::P[k - i], acc);
+    r.l[k - 9] = (u32)acc & FE_MASK;
+    acc >>= FE_W;
+  }
+  r.l[8] = (u32)acc;
+  return r;
+}
+
+// ---------------------------------------------------------------- add / sub
+template <class P, int B1, int B2>
+OZK_HD auto add(const Fe<P, B1>& a, const Fe<P, B2>& b) {
+  Fe<P, B1 + B2> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + b.l[i];
+  fe_carry(r);
+  return r;
+}
+
+template <class P, int B1>
+OZK_HD auto dbl(const Fe<P, B1>& a) {
+  Fe<P, 2 * B1> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = a.l[i] << 1;
+  fe_carry(r);
+  return r;
+}
+
+// a - b + K*p with the smallest K*p that dominates b limb-wise.
+template <class P, int B1, int B2>
+OZK_HD auto sub(const Fe<P, B1>& a, const Fe<P, B2>& b) {
+  constexpr int K = B2 / 16 + 1;
+  static_assert(K <= FE_MAXK, "sub bias table too small");
+  Fe<P, B1 + 16 * K> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + (P::BIAS[K][i] - b.l[i]);
+  fe_carry(r);
+  return r;
+}
+
+template <class P, int B2>
+OZK_HD auto neg(const Fe<P, B2>& b) {
+  constexpr int K = B2 / 16 + 1;
+  static_assert(K <= FE_MAXK, "sub bias table too small");
+  Fe<P, 16 * K> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = P::BIAS[K][i] - b.l[i];
+  fe_carry(r);
+  return r;
+}
+
+// if (a >= K*p) a -= K*p          (branch-free, signed borrow propagation)
+template <int K, class P, int B>
+OZK_HD auto csub(const Fe<P, B>& a) {
+  static_assert(K >= 1 && K <= FE_MAXK, "csub constant out of range");
+  constexpr int BO = (B - 16 * K > 16 * K) ? (B - 16 * K) : 16 * K;
+  Fe<P, BO> r;
+  int32_t c = 0;
+  u32 d[9];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    int32_t t = (int32_t)a.l[i] - (int32_t)P::KP[K][i] + c;
+    d[i] = (u32)t & FE_MASK;
+    c = t >> FE_W;
+  }
+  int32_t top = (int32_t)a.l[8] - (int32_t)P::KP[K][8] + c;
+  d[8] = (u32)top;
+  const bool keep = top < 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = keep ? a.l[i] : d[i];
+  return r;
+}
+
+// reduce to < TB*p/16 (TB >= 16) with the fewest conditional subtractions
+template <int TB, class P, int B>
+OZK_HD auto reduce_to(const Fe<P, B>& a) {
+  if constexpr (B <= TB) {
+    return a;
+  } else {
+    constexpr int KT = TB / 16;  // largest multiple of p not above the target
+    // one csub<KT> lands at max(B-16KT, 16KT) <= TB when B-16KT <= TB; otherwise halve first
+    constexpr int K1 = (B - 16 * KT <= TB) ? KT : ((B + 31) / 32);
+    static_assert(K1 >= 1 && K1 <= FE_MAXK, "reduce_to: K out of range");
+    return reduce_to<TB>(csub<K1>(a));
+  }
+}
+
+// canonical representative in [0, p)
+template <class P, int B>
+OZK_HD Fe<P, 16> canonical(const Fe<P, B>& a) {
+  auto u = csub<1>(Fe<P, 32>(reduce_to<32>(a)));  // < 2p, then one more conditional -p
+  Fe<P, 16> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = u.l[i];
+  return r;
+}
+
+// a == 0 (mod p) ?   a < B*p/16, so a is one of 0, p, 2p, ...
+template <class P, int B>
+OZK_HD bool is_zero(const Fe<P, B>& a) {
+  constexpr int KM = (B + 15) / 16;  // multiples 0..KM-1 are possible
+  bool z = false;
+#pragma unroll
+  for (int k = 0; k < KM; k++) {
+    if (a.l[0] == P::KP[k][0]) {
+      bool e = true;
+#pragma unroll
+      for (int i = 1; i < 9; i++) e = e && (a.l[i] == P::KP[k][i]);
+      z = z || e;
+    }
+  }
+  return z;
+}
+
+template <class P, int B1, int B2>
+OZK_HD bool eq(const Fe<P, B1>& a, const Fe<P, B2>& b) {
+  return is_zero(sub(a, b));
+}
+
+// ---------------------------------------------------------------- pack / unpack
+// 8 x u32 little-endian words (value < 2^256)  <->  9 x 29-bit limbs
+template <class P, int B = 85>
+OZK_HD Fe<P, B> unpack(const u32 (&w)[8]) {
+  Fe<P, B> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    const int bit = FE_W * i, wi = bit / 32, sh = bit % 32;
+    u32 v = w[wi] >> sh;
+    if (sh + FE_W > 32 && wi + 1 < 8) v |= w[wi + 1] << (32 - sh);
+    r.l[i] = (i < 8) ? (v & FE_MASK) : v;
+  }
+  return r;
+}
+
+template <class P, int B>
+OZK_HD void pack(const Fe<P, B>& a, u32 (&w)[8]) {
+  static_assert(B <= 84, "value may not fit 256 bits");
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    // word j = bits [32j, 32j+32)
+    const int lo = (32 * j) / FE_W, sh = (32 * j) % FE_W;
+    u32 v = a.l[lo] >> sh;
+    if (lo + 1 < 9) v |= a.l[lo + 1] << (FE_W - sh);
+    if (FE_W - sh + FE_W < 32 && lo + 2 < 9) v |= a.l[lo + 2] << (2 * FE_W - sh);
+    w[j] = v;
+  }
+}
+
+// wire (canonical, non-Montgomery; any 256-bit value accepted, reduced mod p) -> Montgomery
+template <class P>
+OZK_HD Fe<P, 17> to_mont(const u32 (&w)[8]) {
+  return Fe<P, 17>(mul(unpack<P, 85>(w), fe_const<P, 16>(P::R2)));
+}
+
+// Montgomery -> canonical integer words in [0, p)
+template <class P, int B>
+OZK_HD void from_mont(const Fe<P, B>& a, u32 (&w)[8]) {
+  Fe<P, 1> one = fe_zero<P>();
+  one.l[0] = 1;
+  auto t = mul(a, one);
+  pack(canonical(t), w);
+}
+
+// ---------------------------------------------------------------- inversion (Fermat)
+// a^(p-2); a == 0 -> 0.  Replaces BigInteger.modInverse (Fp.java:90-92).
+template <class P, int B>
+OZK_HD Fe<P, 32> inv(const Fe<P, B>& a_in) {
+  const Fe<P, 32> a = reduce_to<32>(a_in);
+  Fe<P, 32> r = fe_one<P>();
+  for (int i = 253; i >= 0; i--) {
+    r = Fe<P, 32>(sqr(r));
+    if ((P::PM2[i >> 5] >> (i & 31)) & 1) r = Fe<P, 32>(mul(r, a));
+  }
+  return r;
+}
+
+}  // namespace ozk

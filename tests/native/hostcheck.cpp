@@ -1,0 +1,66 @@
+// TEST INFRASTRUCTURE: compiles the device arithmetic headers (fp29.cuh, ec.cuh) for the
+// HOST with g++ so the field / group-law code (and its compile-time bound proofs) can be
+// unit-tested against the oracle without a GPU.  Not linked into the product library.
+#include "../../octopuszk_amd/csrc/ec.cuh"
+#include <string.h>
+using namespace ozk;
+
+
+template <class P>
+static void fe_binop(int op, const u32* a, const u32* b, u32* out) {
+  u32 wa[8], wb[8], wo[8];
+  memcpy(wa, a, 32); memcpy(wb, b, 32);
+  auto x = to_mont<P>(wa); auto y = to_mont<P>(wb);
+  switch (op) {
+    case 0: from_mont(mul(x, y), wo); break;
+    case 1: from_mont(sqr(x), wo); break;
+    case 2: from_mont(add(x, y), wo); break;
+    case 3: from_mont(sub(x, y), wo); break;
+    case 4: from_mont(inv(x), wo); break;
+    case 5: from_mont(neg(x), wo); break;
+    case 6: from_mont(dbl(dbl(dbl(x))), wo); break;
+    case 7: { auto t = sub(sub(sub(x, y), y), y); from_mont(reduce_to<32>(t), wo); break; }
+    case 8: { u32 t[8]; pack(canonical(x), t); auto z = unpack<P, 16>(t); from_mont(z, wo); break; }
+    default: memset(wo, 0, 32);
+  }
+  memcpy(out, wo, 32);
+}
+
+extern "C" void hc_fq_op(int op, const u32* a, const u32* b, u32* out) { fe_binop<FqParams>(op, a, b, out); }
+extern "C" void hc_fr_op(int op, const u32* a, const u32* b, u32* out) { fe_binop<FrParams>(op, a, b, out); }
+extern "C" int hc_fq_is_zero_after_sub(const u32* a, const u32* b) {
+  u32 wa[8], wb[8]; memcpy(wa, a, 32); memcpy(wb, b, 32);
+  return eq(to_mont<FqParams>(wa), to_mont<FqParams>(wb)) ? 1 : 0;
+}
+
+typedef G1Cfg J1;
+typedef G1Cfg::EA A1;
+
+static Jac<J1> load_jac(const u32* w) {  // wire X|Y|Z, 8 words each, canonical
+  u32 t[8]; Jac<J1> p;
+  memcpy(t, w, 32); p.X = to_mont<FqParams>(t);
+  memcpy(t, w + 8, 32); p.Y = to_mont<FqParams>(t);
+  memcpy(t, w + 16, 32); p.Z = to_mont<FqParams>(t);
+  return p;
+}
+static void store_jac(const Jac<J1>& p, u32* w) {
+  u32 t[8];
+  from_mont(p.X, t); memcpy(w, t, 32);
+  from_mont(p.Y, t); memcpy(w + 8, t, 32);
+  from_mont(p.Z, t); memcpy(w + 16, t, 32);
+}
+// op 0: add(P,Q) 1: dbl(P) 2: madd(P, affine(Q.x,Q.y))  3: chain: P + k*Q via repeated madd
+extern "C" void hc_g1_op(int op, const u32* pw, const u32* qw, int k, u32* out) {
+  Jac<J1> p = load_jac(pw), q = load_jac(qw), r;
+  Aff<A1> qa; qa.x = A1(reduce_to<17>(q.X)); qa.y = A1(reduce_to<17>(q.Y));
+  switch (op) {
+    case 0: r = jac_add(p, q); break;
+    case 1: r = jac_dbl(p); break;
+    case 2: r = jac_madd(p, qa); break;
+    case 3: r = p; for (int i = 0; i < k; i++) r = jac_madd(r, qa); break;
+    case 4: r = p; for (int i = 0; i < k; i++) r = jac_add(r, q); break;
+    case 5: r = p; for (int i = 0; i < k; i++) r = jac_dbl(r); break;
+    default: r = p;
+  }
+  store_jac(r, out);
+}

@@ -1,0 +1,116 @@
+"""CPU unit tests of the DEVICE arithmetic headers (fp29.cuh / ec.cuh) compiled for the
+host, against the pure-Python oracle.  Covers the field ops, the lazy-reduction edge
+values, and the group law incl. P+P, P+(-P), infinity (SURVEY.md §7 hard parts)."""
+import ctypes
+import os
+import random
+import subprocess
+
+import pytest
+
+from oracle import bn254 as o
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "native", "hostcheck.cpp")
+LIB = os.path.join(HERE, "native", "_hostcheck.so")
+
+
+@pytest.fixture(scope="module")
+def hc():
+    deps = [SRC] + [os.path.join(HERE, "..", "octopuszk_amd", "csrc", f)
+                    for f in ("fp29.cuh", "ec.cuh", "fq2.cuh", "consts_gen.h")]
+    deps = [d for d in deps if os.path.exists(d)]
+    if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-shared", "-fPIC", "-o", LIB, SRC])
+    return ctypes.CDLL(LIB)
+
+
+def _w(v):
+    return (ctypes.c_uint32 * 8)(*[(v >> (32 * i)) & 0xffffffff for i in range(8)])
+
+
+def _r(buf, n=8):
+    return sum(int(buf[i]) << (32 * i) for i in range(n))
+
+
+def fe_op(hc, field, op, a, b=0):
+    out = (ctypes.c_uint32 * 8)()
+    getattr(hc, "hc_%s_op" % field)(op, _w(a), _w(b), out)
+    return _r(out)
+
+
+EDGE = lambda p: [0, 1, 2, p - 1, p - 2, (p - 1) // 2, (1 << 253), (1 << 29) - 1, 1 << 29,
+                  (1 << 232) - 1, 1 << 232, p >> 1, 3, (1 << 253) + 12345]
+
+
+@pytest.mark.parametrize("field,p", [("fq", o.Q), ("fr", o.R)])
+def test_field_ops(hc, field, p):
+    rng = random.Random(7)
+    vals = EDGE(p) + [rng.randrange(p) for _ in range(200)]
+    for i, a in enumerate(vals):
+        b = vals[(i * 7 + 3) % len(vals)]
+        assert fe_op(hc, field, 0, a, b) == a * b % p
+        assert fe_op(hc, field, 1, a) == a * a % p
+        assert fe_op(hc, field, 2, a, b) == (a + b) % p
+        assert fe_op(hc, field, 3, a, b) == (a - b) % p
+        assert fe_op(hc, field, 5, a) == (-a) % p
+        assert fe_op(hc, field, 6, a) == 8 * a % p
+        assert fe_op(hc, field, 7, a, b) == (a - 3 * b) % p
+        assert fe_op(hc, field, 8, a) == a
+    for a in vals[:40]:
+        want = pow(a, -1, p) if a % p else 0
+        assert fe_op(hc, field, 4, a) == want
+
+
+def test_noncanonical_input_reduced(hc):
+    # any 256-bit wire value is accepted and reduced mod p
+    for a in [o.Q, o.Q + 5, (1 << 256) - 1, 2 * o.Q + 1]:
+        assert fe_op(hc, "fq", 0, a, 1) == a % o.Q
+
+
+def test_eq_mod_p(hc):
+    assert hc.hc_fq_is_zero_after_sub(_w(5), _w(5)) == 1
+    assert hc.hc_fq_is_zero_after_sub(_w(5), _w(6)) == 0
+    assert hc.hc_fq_is_zero_after_sub(_w(0), _w(o.Q)) == 1
+
+
+def _pw(P):
+    return (ctypes.c_uint32 * 24)(*[(c >> (32 * i)) & 0xffffffff for c in P for i in range(8)])
+
+
+def g1_op(hc, op, P, Qp, k=0):
+    out = (ctypes.c_uint32 * 24)()
+    hc.hc_g1_op(op, _pw(P), _pw(Qp), k, out)
+    return tuple(_r(out[8 * i:8 * i + 8]) for i in range(3))
+
+
+def test_g1_group_law(hc):
+    G = o.G1
+    rng = random.Random(11)
+    pts = [G.mul(G.one, rng.randrange(1, o.R)) for _ in range(12)]
+    aff = [G.to_affine(P) for P in pts]
+    for i in range(len(pts)):
+        P, Qa = pts[i], aff[(i + 1) % len(pts)]
+        assert G.equals(g1_op(hc, 0, P, pts[(i + 1) % len(pts)]), G.add(P, Qa))
+        assert G.equals(g1_op(hc, 1, P, P), G.twice(P))
+        assert G.equals(g1_op(hc, 2, P, Qa), G.add(P, Qa))
+    P, Pa = pts[0], aff[0]
+    # doubling and cancellation inside add / madd
+    assert G.equals(g1_op(hc, 0, P, Pa), G.twice(P))
+    assert G.equals(g1_op(hc, 2, P, Pa), G.twice(P))
+    assert G.is_zero(g1_op(hc, 0, P, G.negate(Pa)))
+    assert G.is_zero(g1_op(hc, 2, P, G.negate(Pa)))
+    # infinity on either side
+    assert G.equals(g1_op(hc, 0, G.zero, Pa), P)
+    assert G.equals(g1_op(hc, 0, P, G.zero), P)
+    assert G.equals(g1_op(hc, 2, G.zero, Pa), P)
+    assert G.is_zero(g1_op(hc, 1, G.zero, G.zero))
+    # long chains exercise the loop-carried lazy bounds
+    assert G.equals(g1_op(hc, 3, P, aff[1], 200), G.add(P, G.mul(aff[1], 200)))
+    assert G.equals(g1_op(hc, 4, P, pts[2], 100), G.add(P, G.mul(pts[2], 100)))
+    assert G.equals(g1_op(hc, 5, P, P, 64), G.mul(P, 1 << 64))
+    # repeated base: P + P + P ... hits the doubling branch on the first step
+    assert G.equals(g1_op(hc, 3, Pa, Pa, 5), G.mul(P, 6))
+    # CurvesTest.java:27-82 identities on the HIP group law
+    a = pts[3]
+    assert G.equals(g1_op(hc, 0, G.mul(a, 76749407), G.mul(a, 44410867)), G.mul(a, 121160274))
