@@ -1,0 +1,120 @@
+/* ozk.h — C ABI of the MI355X-native BN254 MSM / FFT back end.
+ *
+ * This is the drop-in boundary: one shared library,
+ * libozk_hip.so, with plain-C entry points (pointers + sizes, no torch / HIP
+ * types).  Each `*_host` function takes exactly the byte buffers the reference's
+ * JNI native receives and returns exactly the bytes it returns; the three JNI
+ * shim libraries (include/ozk_jni.h) only move bytes between the JVM and these.
+ * Each `*_dev` function is the same operation on buffers already resident in HBM
+ * (device pointers), asynchronous on `stream`, for callers that keep data on the
+ * GPU (bench.py, the prove harness, torch.distributed ranks).
+ *
+ * Wire formats (all integers canonical, NON-Montgomery, value < modulus):
+ *   scalar / Fr element in : 32 B little-endian  (VariableBaseMSM.java:121-131)
+ *   G1 point in            : X|Y|Z, 3 x 32 B LE  (VariableBaseMSM.java:221-228)
+ *   G2 point in            : X.c0|X.c1|Y.c0|Y.c1|Z.c0|Z.c1, 6 x 32 B LE
+ *                                                (bn254a/BN254aG2.java:77-86)
+ *   var-MSM / FFT out      : 64 B LE per coordinate, upper 32 B zero
+ *                                                (VariableBaseMSM.java:239-258)
+ *   fixed-base / field out : 64 B BIG-endian per coordinate
+ *                                                (algebra_msm_FixedBaseMSM.cu:783-787)
+ * Returned points are affine-normalised Jacobian triples (X/Z^2, Y/Z^3, 1); the
+ * point at infinity is (0, 1, 0) as BNG1.toAffineCoordinates (BNG1.java:163-172).
+ *
+ * Every function returns 0 on success and a negative OZK_E_* code on failure;
+ * ozk_last_error() gives the message for the calling thread.  Nothing here ever
+ * falls back to a CPU path: without a usable GPU the calls fail with
+ * OZK_E_NO_DEVICE.
+ */
+#ifndef OZK_H
+#define OZK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OZK_OK 0
+#define OZK_E_INVALID -1    /* bad argument (null pointer, n <= 0, not a power of two ...) */
+#define OZK_E_NO_DEVICE -2  /* no HIP device / device call failed */
+#define OZK_E_NOMEM -3      /* device or host allocation failed */
+#define OZK_E_INTERNAL -4
+
+#define OZK_G1 1 /* `type` / `BNType` value for G1; anything else is G2, as in the reference */
+#define OZK_G2 2
+
+const char* ozk_last_error(void);
+int ozk_version(void);
+/* number of visible HIP devices (0 if none); `taskID % count` selects the device as
+ * the reference does (algebra_msm_VariableBaseMSM.cu:1249-1257). */
+int ozk_device_count(void);
+
+/* ---------------- VariableBaseMSM ---------------------------------------
+ * replaces Java_algebra_msm_VariableBaseMSM_variableBaseSerialMSMNativeHelper
+ * (algebra_msm_VariableBaseMSM.h:13-16, .cu:1614-1695).
+ * bases: n x 96 B (G1) or n x 192 B (G2); scalars: n x 32 B; out: 192 B / 384 B. */
+int ozk_var_msm_host(const uint8_t* bases, const uint8_t* scalars, int32_t n, int32_t type,
+                     int32_t task_id, uint8_t* out);
+/* replaces ..._variableBaseDoubleMSMNativeHelper (.h:21-24, .cu:1712-1788).
+ * out: 576 B = G1 result (192) || G2 result (384). */
+int ozk_var_double_msm_host(const uint8_t* bases_g1, const uint8_t* bases_g2,
+                            const uint8_t* scalars, int32_t n, int32_t task_id, uint8_t* out);
+
+/* Device-resident variants.  `workspace` must hold ozk_var_msm_workspace_bytes(n, type)
+ * bytes; all pointers are device pointers; `stream` is a hipStream_t (NULL = default). */
+size_t ozk_var_msm_workspace_bytes(int32_t n, int32_t type);
+int ozk_var_msm_dev(const void* d_bases, const void* d_scalars, int32_t n, int32_t type,
+                    void* d_out, void* d_workspace, size_t workspace_bytes, void* stream);
+/* sum of k affine-normalised partial results in wire-out format (k x 192 B / 384 B), as
+ * produced by ozk_var_msm_dev on k ranks -> one normalised point.  The multi-GPU
+ * reduce(GroupT::add) of VariableBaseMSM.java:777-783 after the RCCL all-gather. */
+int ozk_points_sum_dev(const void* d_points, int32_t k, int32_t type, void* d_out, void* stream);
+
+/* Synthetic inputs for benchmarks / full-size tests (BASELINE.md config 2 generator):
+ * writes n G1 bases P_i = k_i * G, k_i = splitmix64(seed + i) (k_i = 1 if that is 0), in the
+ * wire-in format (affine, Z = 1).  Not part of the reference's surface. */
+int ozk_gen_bases_dev(uint64_t seed, int32_t n, int32_t type, void* d_out_wire, void* stream);
+
+/* ---------------- FixedBaseMSM ------------------------------------------
+ * replaces Java_algebra_msm_FixedBaseMSM_batchMSMNativeHelper
+ * (algebra_msm_FixedBaseMSM.h:13-16, .cu:1276-1384).  out: n x 192 B / n x 384 B (BE). */
+int ozk_fixed_batch_msm_host(int32_t outerc, int32_t window_size, int32_t out_len,
+                             int32_t inner_len, int32_t n, int32_t scalar_size,
+                             const uint8_t* base, const uint8_t* scalars, int32_t bn_type,
+                             int32_t task_id, uint8_t* out);
+/* replaces ..._doubleBatchMSMNativeHelper (.h:21-24, .cu:1395-1491).
+ * out: n x 576 B, per element G1 (3 x 64 BE) || G2 (6 x 64 BE). */
+int ozk_fixed_double_batch_msm_host(int32_t outerc1, int32_t window_size1, int32_t outerc2,
+                                    int32_t window_size2, int32_t out_len1, int32_t inner_len1,
+                                    int32_t out_len2, int32_t inner_len2, int32_t n,
+                                    const uint8_t* base_g1, const uint8_t* base_g2,
+                                    const uint8_t* scalars, int32_t task_id, uint8_t* out);
+/* replaces ..._fieldBatchMSMNativeHelper (.h:29-32, .cu:1500-1558).
+ * in: (n+1) x 32 B LE, element n is the multiplier; out: n x 64 B BE, x_i * b mod r. */
+int ozk_field_batch_mul_host(const uint8_t* in, int32_t n, int32_t task_id, uint8_t* out);
+
+size_t ozk_fixed_batch_msm_workspace_bytes(int32_t outerc, int32_t window_size, int32_t n,
+                                           int32_t bn_type);
+int ozk_fixed_batch_msm_dev(int32_t outerc, int32_t window_size, int32_t n, const void* d_base,
+                            const void* d_scalars, int32_t bn_type, void* d_out,
+                            void* d_workspace, size_t workspace_bytes, void* stream);
+int ozk_field_batch_mul_dev(const void* d_in, int32_t n, void* d_out, void* stream);
+
+/* ---------------- radix-2 FFT over Fr -----------------------------------
+ * replaces Java_algebra_fft_FFTAuxiliary_serialRadix2FFTNativeHelper
+ * (algebra_fft_FFTAuxiliary.h:13-16, .cu:219-260) = FFTAuxiliary.serialRadix2FFT
+ * (FFTAuxiliary.java:60-124).  in: n x 32 B LE (the shim flattens the List<byte[]>),
+ * omega: 32 B LE, out: n x 64 B LE.  n must be a power of two (n == 1: copy). */
+int ozk_fft_host(const uint8_t* in, int32_t n, const uint8_t* omega, int32_t task_id,
+                 uint8_t* out);
+size_t ozk_fft_workspace_bytes(int32_t n);
+/* d_in: n x 32 B LE, d_out: n x 64 B LE (may not alias d_in). */
+int ozk_fft_dev(const void* d_in, int32_t n, const uint8_t* omega_host32, void* d_out,
+                void* d_workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OZK_H */

@@ -1,0 +1,112 @@
+// Packed HBM layouts and wire codecs for curve points, generic over G1 / G2.
+//
+// HBM layouts (all Montgomery form unless "wire"):
+//   coordinate  : CW = 8 (Fq) or 16 (Fq2: c0|c1) little-endian u32 words, value < 2^256
+//   affine base : x|y            = 2*CW words (64 B G1 / 128 B G2), canonical (< p);
+//                 x = y = 0 encodes the point at infinity
+//   Jacobian    : X|Y|Z          = 3*CW words (96 B / 192 B), each coordinate < 4p
+// wire in  (reference JNI input, VariableBaseMSM.java:221-228): 3*CW words, canonical,
+//          non-Montgomery, little-endian.
+// wire out (reference JNI output, VariableBaseMSM.cu:1655-1659): per Fq value 64 B LE,
+//          upper 32 B zero.
+#pragma once
+#include "ec.cuh"
+
+namespace ozk {
+
+// ---- element <-> packed words (overloaded on the element type; Fq2 overloads in fq2.cuh)
+template <class E>
+struct ElemTraits;
+
+template <class P, int B>
+struct ElemTraits<Fe<P, B>> {
+  static constexpr int WORDS = 8;
+  // value stored is < 2^256 and known to respect bound B (caller's contract)
+  static OZK_HD Fe<P, B> load(const u32* p) {
+    u32 w[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = p[i];
+    return unpack<P, B>(w);
+  }
+  static OZK_HD void store(const Fe<P, B>& e, u32* p) {
+    u32 w[8];
+    pack(reduce_to<64>(e), w);
+#pragma unroll
+    for (int i = 0; i < 8; i++) p[i] = w[i];
+  }
+  static OZK_HD Fe<P, B> from_wire(const u32* p) {
+    u32 w[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = p[i];
+    return Fe<P, B>(to_mont<P>(w));
+  }
+  static OZK_HD void to_wire(const Fe<P, B>& e, u32* p) {  // canonical, non-Montgomery
+    u32 w[8];
+    from_mont(e, w);
+#pragma unroll
+    for (int i = 0; i < 8; i++) p[i] = w[i];
+  }
+  // reference return layout: 64 B little-endian per Fq value, upper 32 B zero
+  static OZK_HD void to_wire_out(const Fe<P, B>& e, u32* p) {
+    to_wire(e, p);
+#pragma unroll
+    for (int i = 8; i < 16; i++) p[i] = 0;
+  }
+  static OZK_HD Fe<P, B> from_wire_out(const u32* p) { return from_wire(p); }
+  static OZK_HD bool wire_is_zero(const u32* p) {
+    u32 o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o |= p[i];
+    return o == 0;
+  }
+  static OZK_HD bool wire_is_one(const u32* p) {
+    u32 o = p[0] ^ 1u;
+#pragma unroll
+    for (int i = 1; i < 8; i++) o |= p[i];
+    return o == 0;
+  }
+};
+
+template <class CV>
+struct CurveIO {
+  using EX = typename CV::EX;
+  using EY = typename CV::EY;
+  using EZ = typename CV::EZ;
+  using EA = typename CV::EA;
+  static constexpr int CW = ElemTraits<EA>::WORDS;
+  static constexpr int AFF_WORDS = 2 * CW;
+  static constexpr int JAC_WORDS = 3 * CW;
+
+  static OZK_HD Aff<EA> load_aff(const u32* p) {
+    Aff<EA> q;
+    q.x = ElemTraits<EA>::load(p);
+    q.y = ElemTraits<EA>::load(p + CW);
+    return q;
+  }
+  static OZK_HD void store_aff(const Aff<EA>& q, u32* p) {
+    ElemTraits<EA>::store(q.x, p);
+    ElemTraits<EA>::store(q.y, p + CW);
+  }
+  // stored Jacobian coordinates are < 4p, which is within every EX/EY/EZ bound
+  static OZK_HD Jac<CV> load_jac(const u32* p) {
+    Jac<CV> r;
+    r.X = ElemTraits<EX>::load(p);
+    r.Y = ElemTraits<EY>::load(p + CW);
+    r.Z = ElemTraits<EZ>::load(p + 2 * CW);
+    return r;
+  }
+  static OZK_HD void store_jac(const Jac<CV>& r, u32* p) {
+    ElemTraits<EX>::store(r.X, p);
+    ElemTraits<EY>::store(r.Y, p + CW);
+    ElemTraits<EZ>::store(r.Z, p + 2 * CW);
+  }
+  static OZK_HD Jac<CV> jac_from_wire(const u32* p) {
+    Jac<CV> r;
+    r.X = ElemTraits<EX>::from_wire(p);
+    r.Y = ElemTraits<EY>::from_wire(p + CW);
+    r.Z = ElemTraits<EZ>::from_wire(p + 2 * CW);
+    return r;
+  }
+};
+
+}  // namespace ozk

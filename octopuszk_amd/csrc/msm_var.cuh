@@ -1,0 +1,434 @@
+// Variable-base MSM (Pippenger bucket method) for gfx950 — kernels.
+//
+// Replaces the per-window CUDA pipeline of the reference
+// (algebra_msm_VariableBaseMSM.cu:736-1241 kernels, :1246-1428 driver; SURVEY.md §2a,
+// §8a rows V5-V9) and computes the same group element as the serial Java
+// VariableBaseMSM.pippengerMSM (VariableBaseMSM.java:134-188): sum_i s_i * P_i.
+// The window size, bucket order and addition order differ from the reference (any
+// order gives the same group element); the result is affine-normalised so its bytes
+// are unique.
+//
+// Pipeline (one launch each, all windows at once, no host round trips):
+//   convert   bases wire (Jacobian, canonical) -> affine Montgomery, 64 B records
+//   digits    scalars -> c-bit digits per window, histogram + rank by returning atomics
+//   scan      exclusive prefix sum of the W*2^c histogram
+//   scatter   counting-sort scatter of point indices by (window, digit)
+//   segreduce level 1: every lane takes L consecutive sorted entries and madd-accumulates
+//             runs of equal bucket id; complete runs go to the bucket array, runs cut by
+//             a chunk boundary become "partials" (2 slots per lane)
+//             level >= 2: same scheme over the partial slots with Jacobian adds, until
+//             one lane remains — load-balanced for ANY digit distribution (a bucket
+//             holding half the input is summed by N/2L lanes, not by one)
+//   wsum      per-window  sum_d d*B_d  by segmented running sums, 8 buckets per lane/level
+//   finalize  Horner over the windows, affine normalisation, wire-out bytes
+#pragma once
+#include "curve.cuh"
+
+namespace ozk {
+
+constexpr u32 BID_NONE = 0xffffffffu;
+
+struct MsmPlan {
+  int n;        // points
+  int c;        // window bits (<= 16)
+  int W;        // windows = ceil(256 / c)
+  int L1;       // sorted entries per lane at level 1
+  int LK;       // slots per lane at levels >= 2
+  int S;        // buckets per lane per wsum level (power of two)
+};
+
+OZK_HD u32 scalar_digit(const u32 (&s)[8], int w, int c) {
+  const int bit = w * c;
+  const int wi = bit >> 5, sh = bit & 31;
+  u32 v = s[wi] >> sh;
+  if (sh + c > 32 && wi + 1 < 8) v |= s[wi + 1] << (32 - sh);
+  return v & ((1u << c) - 1u);
+}
+
+#if defined(__HIPCC__)
+
+// ------------------------------------------------------------------ convert
+// One lane per base.  Z == 1 (the prover's normal case: keys produced by this library
+// are affine) costs 2 Montgomery conversions; Z == 0 -> infinity marker; any other Z is
+// normalised with a per-lane Fermat inversion (correct for reference-produced
+// Jacobian keys, slower).
+template <class CV>
+__global__ void __launch_bounds__(256) k_convert_bases(const u32* __restrict__ wire,
+                                                       u32* __restrict__ aff, int n) {
+  using IO = CurveIO<CV>;
+  using EA = typename CV::EA;
+  using ET = ElemTraits<EA>;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u32* p = wire + (size_t)i * IO::JAC_WORDS;
+  u32* o = aff + (size_t)i * IO::AFF_WORDS;
+  Aff<EA> q;
+  if (ET::wire_is_zero(p + 2 * IO::CW)) {
+    q.x = EA(el_zero(q.x));
+    q.y = EA(el_zero(q.x));
+  } else if (ET::wire_is_one(p + 2 * IO::CW)) {
+    q.x = ET::from_wire(p);
+    q.y = ET::from_wire(p + IO::CW);
+  } else {
+    const EA X = ET::from_wire(p), Y = ET::from_wire(p + IO::CW), Z = ET::from_wire(p + 2 * IO::CW);
+    const auto zi = inv(Z);
+    if (is_zero(Z)) {  // Z == p etc.: still infinity
+      q.x = EA(el_zero(q.x));
+      q.y = EA(el_zero(q.x));
+    } else {
+      const auto zi2 = sqr(zi);
+      q.x = EA(canonical(mul(X, zi2)));
+      q.y = EA(canonical(mul(Y, mul(zi2, zi))));
+    }
+  }
+  // canonical (< p) so that equal points have equal records
+  q.x = EA(canonical(q.x));
+  q.y = EA(canonical(q.y));
+  IO::store_aff(q, o);
+}
+
+// ------------------------------------------------------------------ digits + histogram
+// digits[w*n + i] (u16), ranks[w*n + i] (u32): rank of entry among its bucket.
+__global__ void __launch_bounds__(256) k_digits(const u32* __restrict__ scalars, int n, int c, int W,
+                                                u32* __restrict__ hist, uint16_t* __restrict__ digits,
+                                                u32* __restrict__ ranks) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < n;
+  u32 s[8];
+  if (live) {
+    const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
+    const uint4 a = sp[0], b = sp[1];
+    s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w;
+    s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; k++) s[k] = 0;
+  }
+  const int lane = threadIdx.x & 63;
+  for (int w = 0; w < W; w++) {
+    const u32 d = live ? scalar_digit(s, w, c) : 0u;
+    const bool nz = d != 0;
+    const unsigned long long m = __ballot(nz);
+    u32 rank = 0;
+    if (m != 0ull) {
+      // wave-aggregated atomic when every live digit in the wave is the same bucket
+      // (skewed inputs: Fp.random-style scalars put whole waves into one bucket)
+      const int leader = __ffsll((long long)m) - 1;
+      const u32 dl = __shfl(d, leader);
+      const bool same = __all(!nz || d == dl);
+      if (same) {
+        u32 base = 0;
+        if (lane == leader) base = atomicAdd(&hist[((u32)w << c) | dl], (u32)__popcll(m));
+        base = __shfl(base, leader);
+        rank = base + (u32)__popcll(m & ((1ull << lane) - 1ull));
+      } else if (nz) {
+        rank = atomicAdd(&hist[((u32)w << c) | d], 1u);
+      }
+    }
+    if (live) {
+      digits[(size_t)w * n + i] = (uint16_t)d;
+      ranks[(size_t)w * n + i] = rank;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ exclusive scan (3 kernels)
+constexpr int SCAN_ITEMS = 16;   // per lane
+constexpr int SCAN_BLOCK = 256;  // lanes -> 4096 items per block
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_blocksum(const u32* __restrict__ in, int n,
+                                                              u32* __restrict__ blocksum) {
+  __shared__ u32 sh[SCAN_BLOCK / 64];
+  const size_t base = (size_t)blockIdx.x * SCAN_BLOCK * SCAN_ITEMS + (size_t)threadIdx.x * SCAN_ITEMS;
+  u32 s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) s += (base + k < (size_t)n) ? in[base + k] : 0u;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 t = 0;
+    for (int k = 0; k < SCAN_BLOCK / 64; k++) t += sh[k];
+    blocksum[blockIdx.x] = t;
+  }
+}
+// single block: exclusive scan of nb block sums in place; total -> *total
+__global__ void __launch_bounds__(1024) k_scan_top(u32* __restrict__ blocksum, int nb, u32* __restrict__ total) {
+  __shared__ u32 sh[1024];
+  __shared__ u32 carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nb; base += 1024) {
+    const int i = base + threadIdx.x;
+    const u32 v = (i < nb) ? blocksum[i] : 0u;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      const u32 t = (threadIdx.x >= (unsigned)o) ? sh[threadIdx.x - o] : 0u;
+      __syncthreads();
+      sh[threadIdx.x] += t;
+      __syncthreads();
+    }
+    const u32 incl = sh[threadIdx.x];
+    if (i < nb) blocksum[i] = carry + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_final(const u32* __restrict__ in, int n,
+                                                           const u32* __restrict__ blocksum,
+                                                           u32* __restrict__ out) {
+  __shared__ u32 sh[SCAN_BLOCK / 64];
+  const size_t base = (size_t)blockIdx.x * SCAN_BLOCK * SCAN_ITEMS + (size_t)threadIdx.x * SCAN_ITEMS;
+  u32 v[SCAN_ITEMS];
+  u32 s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) {
+    v[k] = (base + k < (size_t)n) ? in[base + k] : 0u;
+    s += v[k];
+  }
+  // inclusive scan of lane sums across the wave
+  u32 incl = s;
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const u32 t = __shfl_up(incl, o);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) sh[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  u32 wave_off = 0;
+  for (int k = 0; k < (int)(threadIdx.x >> 6); k++) wave_off += sh[k];
+  u32 run = blocksum[blockIdx.x] + wave_off + incl - s;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) {
+    if (base + k < (size_t)n) out[base + k] = run;
+    run += v[k];
+  }
+}
+
+// ------------------------------------------------------------------ scatter
+__global__ void __launch_bounds__(256) k_scatter(const uint16_t* __restrict__ digits,
+                                                 const u32* __restrict__ ranks,
+                                                 const u32* __restrict__ offs, int n, int c,
+                                                 u32* __restrict__ sidx, u32* __restrict__ sbid) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int w = blockIdx.y;
+  if (i >= n) return;
+  const u32 d = digits[(size_t)w * n + i];
+  if (d == 0) return;
+  const u32 b = ((u32)w << c) | d;
+  const u32 pos = offs[b] + ranks[(size_t)w * n + i];
+  sidx[pos] = (u32)i;
+  sbid[pos] = b;
+}
+
+// ------------------------------------------------------------------ segmented reduction
+// Lane t owns input positions [t*L, min((t+1)*L, n_in)).  A maximal run of equal bucket id
+// that lies entirely inside the chunk is complete -> buckets[bid].  A run cut by the chunk
+// start and/or end is a partial: the cut-at-start run goes to slot 2t, the cut-at-end run
+// to slot 2t+1 (a run cut on both sides fills 2t and puts an infinity with the same id in
+// 2t+1), so pieces of one bucket stay adjacent in slot order and the next level can apply
+// the same rule.  Unused slots carry BID_NONE.  Each bucket is written exactly once, at
+// the level where its last pieces meet.
+template <class CV, bool FIRST>
+__global__ void __launch_bounds__(256)
+k_segreduce(const u32* __restrict__ bid_in, const u32* __restrict__ idx_in,
+            const u32* __restrict__ pts_in,  // FIRST: affine bases; else Jacobian slots
+            const u32* __restrict__ d_count, int n_in_static, int L,
+            u32* __restrict__ buckets, u32* __restrict__ bid_out, u32* __restrict__ pts_out,
+            int n_lanes) {
+  using IO = CurveIO<CV>;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_lanes) return;
+  const long long n_in = FIRST ? (long long)(*d_count) : (long long)n_in_static;
+  const long long s = (long long)t * L;
+  u32 head_bid = BID_NONE, tail_bid = BID_NONE;
+  if (s < n_in) {
+    const long long e = (s + L < n_in) ? (s + L) : n_in;
+    const u32 first_bid = bid_in[s];
+    const bool cb = (s > 0) && (bid_in[s - 1] == first_bid) && (first_bid != BID_NONE);
+    const u32 last_bid = bid_in[e - 1];
+    const bool cf = (e < n_in) && (bid_in[e] == last_bid) && (last_bid != BID_NONE);
+    u32 cur = BID_NONE;
+    bool cur_cb = false;
+    Jac<CV> acc = jac_infinity<CV>();
+    for (long long p = s; p < e; p++) {
+      const u32 b = bid_in[p];
+      if (b != cur) {
+        if (cur != BID_NONE) {  // run [.., p) ended inside the chunk
+          if (cur_cb) {
+            head_bid = cur;
+            IO::store_jac(acc, pts_out + (size_t)(2 * (size_t)t) * IO::JAC_WORDS);
+          } else {
+            IO::store_jac(acc, buckets + (size_t)cur * IO::JAC_WORDS);
+          }
+        }
+        cur = b;
+        cur_cb = (p == s) && cb;
+        if (b != BID_NONE) {
+          if constexpr (FIRST) {
+            acc = from_affine<CV>(IO::load_aff(pts_in + (size_t)idx_in[p] * IO::AFF_WORDS));
+          } else {
+            acc = IO::load_jac(pts_in + (size_t)p * IO::JAC_WORDS);
+          }
+        }
+      } else if (b != BID_NONE) {
+        if constexpr (FIRST) {
+          acc = jac_madd(acc, IO::load_aff(pts_in + (size_t)idx_in[p] * IO::AFF_WORDS));
+        } else {
+          acc = jac_add(acc, IO::load_jac(pts_in + (size_t)p * IO::JAC_WORDS));
+        }
+      }
+    }
+    if (cur != BID_NONE) {  // last run of the chunk
+      if (cur_cb) {
+        head_bid = cur;
+        IO::store_jac(acc, pts_out + (size_t)(2 * (size_t)t) * IO::JAC_WORDS);
+        if (cf) {  // cut on both sides: neutral element keeps the pieces adjacent
+          tail_bid = cur;
+          IO::store_jac(jac_infinity<CV>(), pts_out + (size_t)(2 * (size_t)t + 1) * IO::JAC_WORDS);
+        }
+      } else if (cf) {
+        tail_bid = cur;
+        IO::store_jac(acc, pts_out + (size_t)(2 * (size_t)t + 1) * IO::JAC_WORDS);
+      } else {
+        IO::store_jac(acc, buckets + (size_t)cur * IO::JAC_WORDS);
+      }
+    }
+  }
+  bid_out[2 * (size_t)t] = head_bid;
+  bid_out[2 * (size_t)t + 1] = tail_bid;
+}
+
+// ------------------------------------------------------------------ window sums
+// Per window the elements e = 0..m-1 carry (A_e, R_e) with
+//     S_w = sum_e A_e + 2^g * sum_e e * R_e.
+// Level 0: elements are the buckets (A = infinity, R = B_d, g = 0).  One level with
+// segments of S = 2^sg elements turns segment j into
+//     A'_j = sum A_e + 2^g * sum (e - jS) R_e,   R'_j = sum R_e,   g' = g + sg.
+// FIRSTLEVEL reads R from the bucket array (skipping buckets whose histogram count is 0:
+// they were never written, so the bucket array needs no clearing) and has no A.
+template <class CV, bool FIRSTLEVEL>
+__global__ void __launch_bounds__(256)
+k_wsum(const u32* __restrict__ A_in, const u32* __restrict__ R_in, const u32* __restrict__ hist,
+       int m_in, int S, int g, u32* __restrict__ A_out, u32* __restrict__ R_out, int m_out, int W) {
+  using IO = CurveIO<CV>;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= m_out * W) return;
+  const int w = t / m_out, j = t - w * m_out;
+  const size_t base = (size_t)w * m_in;
+  const int lo = j * S;
+  int hi = lo + S;
+  if (hi > m_in) hi = m_in;
+  Jac<CV> run = jac_infinity<CV>(), ws = jac_infinity<CV>(), asum = jac_infinity<CV>();
+  for (int e = hi - 1; e >= lo; e--) {
+    if constexpr (FIRSTLEVEL) {
+      // buckets no entry was sorted into were never written: treat as infinity
+      if (hist[base + e] != 0) run = jac_add(run, IO::load_jac(R_in + (base + e) * IO::JAC_WORDS));
+    } else {
+      run = jac_add(run, IO::load_jac(R_in + (base + e) * IO::JAC_WORDS));
+    }
+    if (e > lo) ws = jac_add(ws, run);  // after the loop: sum (e - lo) * R_e
+    if constexpr (!FIRSTLEVEL) asum = jac_add(asum, IO::load_jac(A_in + (base + e) * IO::JAC_WORDS));
+  }
+  for (int k = 0; k < g; k++) ws = jac_dbl(ws);
+  if constexpr (!FIRSTLEVEL) ws = jac_add(ws, asum);
+  IO::store_jac(ws, A_out + ((size_t)w * m_out + j) * IO::JAC_WORDS);
+  IO::store_jac(run, R_out + ((size_t)w * m_out + j) * IO::JAC_WORDS);
+}
+
+// ------------------------------------------------------------------ finalize
+// affine-normalise and emit the reference's return layout: per Fq value 64 B LE, upper
+// 32 B zero (VariableBaseMSM.cu:1655-1659); infinity -> (0, 1, 0) (BNG1.java:163-172).
+template <class CV>
+__device__ void write_normalised(const Jac<CV>& r, u32* out) {
+  using EA = typename CV::EA;
+  using ET = ElemTraits<EA>;
+  constexpr int OW = 2 * ET::WORDS;  // wire-out words per coordinate
+  if (is_inf(r)) {
+    ET::to_wire_out(EA(el_zero(r.X)), out);
+    ET::to_wire_out(EA(el_one(r.X)), out + OW);
+    ET::to_wire_out(EA(el_zero(r.X)), out + 2 * OW);
+  } else {
+    const auto zi = inv(r.Z);
+    const auto zi2 = sqr(zi);
+    ET::to_wire_out(EA(reduce_to<17>(mul(r.X, zi2))), out);
+    ET::to_wire_out(EA(reduce_to<17>(mul(r.Y, mul(zi2, zi)))), out + OW);
+    ET::to_wire_out(EA(el_one(r.X)), out + 2 * OW);
+  }
+}
+
+// A_w holds S_w (one element per window after the last wsum level, with 2^g * 0 * R = 0).
+template <class CV>
+__global__ void k_finalize(const u32* __restrict__ A_w, int W, int c, u32* __restrict__ out) {
+  using IO = CurveIO<CV>;
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  Jac<CV> r = jac_infinity<CV>();
+  for (int w = W - 1; w >= 0; w--) {
+    for (int k = 0; k < c; k++) r = jac_dbl(r);  // no-op while r is infinity
+    r = jac_add(r, IO::load_jac(A_w + (size_t)w * IO::JAC_WORDS));
+  }
+  write_normalised<CV>(r, out);
+}
+
+// sum of k points given in wire-out format (affine or (0,1,0)); used for the multi-GPU reduce
+template <class CV>
+__global__ void k_points_sum(const u32* __restrict__ pts, int k, u32* __restrict__ out) {
+  using EA = typename CV::EA;
+  using ET = ElemTraits<EA>;
+  constexpr int OW = 2 * ET::WORDS;
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  Jac<CV> r = jac_infinity<CV>();
+  for (int i = 0; i < k; i++) {
+    const u32* p = pts + (size_t)i * 3 * OW;
+    Jac<CV> q;
+    q.X = ET::from_wire_out(p);
+    q.Y = ET::from_wire_out(p + OW);
+    q.Z = ET::from_wire_out(p + 2 * OW);
+    r = jac_add(r, q);
+  }
+  write_normalised<CV>(r, out);
+}
+
+// ------------------------------------------------------------------ synthetic bases
+// Bench/test utility (BASELINE.md config inputs): P_i = k_i * G with k_i = splitmix64(seed + i),
+// written in the JNI wire-in format (affine, Z = 1).  Known discrete logs make the full-size
+// MSM checkable on the CPU: sum s_i P_i = (sum s_i k_i mod r) * G.
+OZK_HD u64 splitmix64(u64 x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+template <class CV>
+__global__ void __launch_bounds__(256) k_gen_bases(u64 seed, int n, const u32* __restrict__ gen_wire,
+                                                   u32* __restrict__ out_wire) {
+  using IO = CurveIO<CV>;
+  using EA = typename CV::EA;
+  using ET = ElemTraits<EA>;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u64 k = splitmix64(seed + (u64)i);
+  if (k == 0) k = 1;
+  Aff<EA> g;
+  g.x = ET::from_wire(gen_wire);
+  g.y = ET::from_wire(gen_wire + IO::CW);
+  Jac<CV> r = jac_infinity<CV>();
+  for (int b = 63; b >= 0; b--) {
+    r = jac_dbl(r);
+    if ((k >> b) & 1) r = jac_madd(r, g);
+  }
+  const auto zi = inv(r.Z);
+  const auto zi2 = sqr(zi);
+  u32* o = out_wire + (size_t)i * IO::JAC_WORDS;
+  ET::to_wire(EA(reduce_to<17>(mul(r.X, zi2))), o);
+  ET::to_wire(EA(reduce_to<17>(mul(r.Y, mul(zi2, zi)))), o + IO::CW);
+  ET::to_wire(EA(el_one(r.X)), o + 2 * IO::CW);
+}
+
+#endif  // __HIPCC__
+
+}  // namespace ozk

@@ -1,0 +1,289 @@
+// Variable-base MSM: host driver + C ABI (include/ozk.h).
+// Replaces pippengerMSMG1 / pippengerMSMG2 (algebra_msm_VariableBaseMSM.cu:1246-1604) and
+// the two JNI natives of algebra.msm.VariableBaseMSM (.cu:1614-1788).
+#include <stdlib.h>
+
+#include <vector>
+
+#include "msm_var.cuh"
+#include "ozk_common.h"
+#if defined(OZK_WITH_G2)
+#include "fq2.cuh"
+#endif
+
+namespace ozk {
+
+static MsmPlan make_plan(int n) {
+  MsmPlan p;
+  p.n = n;
+  int c = ilog2((uint32_t)n) - 4;
+  if (c < 4) c = 4;
+  if (c > 16) c = 16;
+  c = env_int("OZK_MSM_C", c);
+  if (c < 1) c = 1;
+  if (c > 16) c = 16;
+  p.c = c;
+  p.W = (256 + c - 1) / c;
+  p.L1 = env_int("OZK_MSM_L1", 16);
+  p.LK = env_int("OZK_MSM_LK", 16);
+  if (p.L1 < 2) p.L1 = 2;
+  if (p.LK < 4) p.LK = 4;
+  int S = env_int("OZK_MSM_S", 8);
+  int sg = ilog2((uint32_t)(S < 2 ? 2 : S));
+  p.S = 1 << sg;
+  return p;
+}
+
+struct MsmLayout {
+  // all device pointers into the workspace
+  u32* aff;
+  u32 *hist, *offs, *blocksum, *total;
+  uint16_t* digits;
+  u32 *ranks, *sidx, *sbid;
+  u32* buckets;
+  u32 *slot_bid[2], *slot_pts[2];
+  u32 *wA[2], *wR[2];
+  size_t bytes;
+  size_t cap;   // n * W sorted entries at most
+  size_t NB;    // W << c buckets
+  size_t slots0, slots1;
+  size_t m1;    // wsum elements per window after the first level
+};
+
+template <class CV>
+static MsmLayout make_layout(const MsmPlan& p, void* ws, size_t ws_bytes) {
+  using IO = CurveIO<CV>;
+  MsmLayout L;
+  Bump b(ws, ws_bytes);
+  L.cap = (size_t)p.n * p.W;
+  L.NB = (size_t)p.W << p.c;
+  L.aff = b.take<u32>((size_t)p.n * IO::AFF_WORDS);
+  L.hist = b.take<u32>(L.NB);
+  L.offs = b.take<u32>(L.NB);
+  L.blocksum = b.take<u32>(L.NB / (SCAN_BLOCK * SCAN_ITEMS) + 2);
+  L.total = b.take<u32>(4);
+  L.digits = b.take<uint16_t>(L.cap);
+  L.ranks = b.take<u32>(L.cap);
+  L.sidx = b.take<u32>(L.cap);
+  L.sbid = b.take<u32>(L.cap + 1);
+  L.buckets = b.take<u32>(L.NB * IO::JAC_WORDS);
+  const size_t T1 = (L.cap + p.L1 - 1) / p.L1;
+  L.slots0 = 2 * T1;
+  const size_t T2 = (L.slots0 + p.LK - 1) / p.LK;
+  L.slots1 = 2 * T2;
+  L.slot_bid[0] = b.take<u32>(L.slots0);
+  L.slot_pts[0] = b.take<u32>(L.slots0 * IO::JAC_WORDS);
+  L.slot_bid[1] = b.take<u32>(L.slots1);
+  L.slot_pts[1] = b.take<u32>(L.slots1 * IO::JAC_WORDS);
+  L.m1 = (((size_t)1 << p.c) + p.S - 1) / p.S;
+  for (int k = 0; k < 2; k++) {
+    L.wA[k] = b.take<u32>((size_t)p.W * L.m1 * IO::JAC_WORDS);
+    L.wR[k] = b.take<u32>((size_t)p.W * L.m1 * IO::JAC_WORDS);
+  }
+  b.take<u32>(64);
+  L.bytes = b.off;
+  return L;
+}
+
+template <class CV>
+static int var_msm_dev(const void* d_bases, const void* d_scalars, int n, void* d_out, void* ws,
+                       size_t ws_bytes, hipStream_t st) {
+  const MsmPlan p = make_plan(n);
+  const MsmLayout L = make_layout<CV>(p, ws, ws_bytes);
+  if (L.bytes > ws_bytes)
+    return fail(OZK_E_INVALID, "workspace too small: need %zu bytes, got %zu", L.bytes, ws_bytes);
+  const int TB = 256;
+  const u32* bases = (const u32*)d_bases;
+  const u32* scalars = (const u32*)d_scalars;
+
+  OZK_HIP(hipMemsetAsync(L.hist, 0, L.NB * sizeof(u32), st));
+  hipLaunchKernelGGL((k_convert_bases<CV>), dim3((n + TB - 1) / TB), dim3(TB), 0, st, bases, L.aff, n);
+  hipLaunchKernelGGL(k_digits, dim3((n + TB - 1) / TB), dim3(TB), 0, st, scalars, n, p.c, p.W, L.hist,
+                     L.digits, L.ranks);
+  // exclusive scan of the histogram -> bucket offsets, total entry count M
+  const int items = SCAN_BLOCK * SCAN_ITEMS;
+  const int nb = (int)((L.NB + items - 1) / items);
+  hipLaunchKernelGGL(k_scan_blocksum, dim3(nb), dim3(SCAN_BLOCK), 0, st, L.hist, (int)L.NB, L.blocksum);
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, L.blocksum, nb, L.total);
+  hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_BLOCK), 0, st, L.hist, (int)L.NB, L.blocksum, L.offs);
+  hipLaunchKernelGGL(k_scatter, dim3((n + TB - 1) / TB, p.W), dim3(TB), 0, st, L.digits, L.ranks, L.offs, n,
+                     p.c, L.sidx, L.sbid);
+  // level 1 over the sorted entries
+  size_t lanes = (L.cap + p.L1 - 1) / p.L1;
+  hipLaunchKernelGGL((k_segreduce<CV, true>), dim3((unsigned)((lanes + TB - 1) / TB)), dim3(TB), 0, st,
+                     L.sbid, L.sidx, L.aff, L.total, 0, p.L1, L.buckets, L.slot_bid[0], L.slot_pts[0],
+                     (int)lanes);
+  // levels >= 2 over the partial slots, ping-pong, until a single lane has seen everything
+  size_t n_in = 2 * lanes;
+  int cur = 0;
+  while (true) {
+    lanes = (n_in + p.LK - 1) / p.LK;
+    hipLaunchKernelGGL((k_segreduce<CV, false>), dim3((unsigned)((lanes + TB - 1) / TB)), dim3(TB), 0, st,
+                       L.slot_bid[cur], (const u32*)nullptr, L.slot_pts[cur], (const u32*)nullptr,
+                       (int)n_in, p.LK, L.buckets, L.slot_bid[cur ^ 1], L.slot_pts[cur ^ 1], (int)lanes);
+    if (lanes == 1) break;
+    n_in = 2 * lanes;
+    cur ^= 1;
+  }
+  // window sums
+  int m_in = 1 << p.c, g = 0, k = 0;
+  const int sg = ilog2((uint32_t)p.S);
+  {
+    const int m_out = (m_in + p.S - 1) / p.S;
+    const int tot = m_out * p.W;
+    hipLaunchKernelGGL((k_wsum<CV, true>), dim3((tot + TB - 1) / TB), dim3(TB), 0, st, (const u32*)nullptr,
+                       L.buckets, L.hist, m_in, p.S, g, L.wA[0], L.wR[0], m_out, p.W);
+    m_in = m_out;
+    g += sg;
+  }
+  while (m_in > 1) {
+    const int m_out = (m_in + p.S - 1) / p.S;
+    const int tot = m_out * p.W;
+    hipLaunchKernelGGL((k_wsum<CV, false>), dim3((tot + TB - 1) / TB), dim3(TB), 0, st, L.wA[k], L.wR[k],
+                       (const u32*)nullptr, m_in, p.S, g, L.wA[k ^ 1], L.wR[k ^ 1], m_out, p.W);
+    m_in = m_out;
+    g += sg;
+    k ^= 1;
+  }
+  hipLaunchKernelGGL((k_finalize<CV>), dim3(1), dim3(64), 0, st, L.wA[k], p.W, p.c, (u32*)d_out);
+  OZK_HIP(hipGetLastError());
+  return OZK_OK;
+}
+
+template <class CV>
+static size_t var_msm_ws_bytes(int n) {
+  return make_layout<CV>(make_plan(n), nullptr, 0).bytes;
+}
+
+// host-buffer variant: H2D, run, D2H.  Buffers are per call (re-entrant; callers are
+// concurrent Spark task threads in the reference, SURVEY.md §8b "Threading").
+template <class CV>
+static int var_msm_host(const uint8_t* bases, const uint8_t* scalars, int n, int task_id, uint8_t* out) {
+  using IO = CurveIO<CV>;
+  int rc = select_device(task_id);
+  if (rc) return rc;
+  const size_t base_bytes = (size_t)n * IO::JAC_WORDS * 4, sc_bytes = (size_t)n * 32;
+  const size_t out_bytes = (size_t)IO::JAC_WORDS * 8;
+  const size_t ws_bytes = var_msm_ws_bytes<CV>(n);
+  uint8_t* d = nullptr;
+  hipStream_t st = nullptr;
+  OZK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  hipError_t e = hipMalloc((void**)&d, base_bytes + sc_bytes + out_bytes + ws_bytes + 1024);
+  if (e != hipSuccess) {
+    hipStreamDestroy(st);
+    return fail(OZK_E_NOMEM, "hipMalloc(%zu) failed: %s", base_bytes + sc_bytes + ws_bytes, hipGetErrorString(e));
+  }
+  uint8_t* d_bases = d;
+  uint8_t* d_sc = d_bases + ((base_bytes + 255) & ~(size_t)255);
+  uint8_t* d_out = d_sc + ((sc_bytes + 255) & ~(size_t)255);
+  uint8_t* d_ws = d_out + 256 * ((out_bytes + 255) / 256);
+  rc = OZK_OK;
+  do {
+    if ((e = hipMemcpyAsync(d_bases, bases, base_bytes, hipMemcpyHostToDevice, st)) != hipSuccess) break;
+    if ((e = hipMemcpyAsync(d_sc, scalars, sc_bytes, hipMemcpyHostToDevice, st)) != hipSuccess) break;
+    rc = var_msm_dev<CV>(d_bases, d_sc, n, d_out, d_ws, ws_bytes, st);
+    if (rc) break;
+    if ((e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, st)) != hipSuccess) break;
+    e = hipStreamSynchronize(st);
+  } while (0);
+  hipFree(d);
+  hipStreamDestroy(st);
+  if (rc) return rc;
+  if (e != hipSuccess) return fail(OZK_E_NO_DEVICE, "HIP failure in var_msm_host: %s", hipGetErrorString(e));
+  return OZK_OK;
+}
+
+}  // namespace ozk
+
+using namespace ozk;
+
+extern "C" {
+
+size_t ozk_var_msm_workspace_bytes(int32_t n, int32_t type) {
+  if (n <= 0) return 0;
+  if (type == OZK_G1) return var_msm_ws_bytes<G1Cfg>(n);
+#if defined(OZK_WITH_G2)
+  return var_msm_ws_bytes<G2Cfg>(n);
+#else
+  return 0;
+#endif
+}
+
+int ozk_var_msm_dev(const void* d_bases, const void* d_scalars, int32_t n, int32_t type, void* d_out,
+                    void* d_workspace, size_t workspace_bytes, void* stream) {
+  if (!d_bases || !d_scalars || !d_out || !d_workspace) return fail(OZK_E_INVALID, "null pointer argument");
+  if (n <= 0 || n > (1 << 24)) return fail(OZK_E_INVALID, "batch_size %d out of range [1, 2^24]", n);
+  if (type == OZK_G1)
+    return var_msm_dev<G1Cfg>(d_bases, d_scalars, n, d_out, d_workspace, workspace_bytes, (hipStream_t)stream);
+#if defined(OZK_WITH_G2)
+  return var_msm_dev<G2Cfg>(d_bases, d_scalars, n, d_out, d_workspace, workspace_bytes, (hipStream_t)stream);
+#else
+  return fail(OZK_E_INVALID, "G2 not built");
+#endif
+}
+
+int ozk_var_msm_host(const uint8_t* bases, const uint8_t* scalars, int32_t n, int32_t type, int32_t task_id,
+                     uint8_t* out) {
+  if (!bases || !scalars || !out) return fail(OZK_E_INVALID, "null pointer argument");
+  if (n <= 0 || n > (1 << 24)) return fail(OZK_E_INVALID, "batch_size %d out of range [1, 2^24]", n);
+  if (type == OZK_G1) return var_msm_host<G1Cfg>(bases, scalars, n, task_id, out);
+#if defined(OZK_WITH_G2)
+  return var_msm_host<G2Cfg>(bases, scalars, n, task_id, out);
+#else
+  return fail(OZK_E_INVALID, "G2 not built");
+#endif
+}
+
+int ozk_var_double_msm_host(const uint8_t* bases_g1, const uint8_t* bases_g2, const uint8_t* scalars,
+                            int32_t n, int32_t task_id, uint8_t* out) {
+  // G1 then G2 on the same scalars (VariableBaseMSM.cu:1772-1773); out = G1 (192) || G2 (384)
+  int rc = ozk_var_msm_host(bases_g1, scalars, n, OZK_G1, task_id, out);
+  if (rc) return rc;
+  return ozk_var_msm_host(bases_g2, scalars, n, OZK_G2, task_id, out + 192);
+}
+
+int ozk_points_sum_dev(const void* d_points, int32_t k, int32_t type, void* d_out, void* stream) {
+  if (!d_points || !d_out || k <= 0) return fail(OZK_E_INVALID, "bad argument");
+  if (type == OZK_G1) {
+    hipLaunchKernelGGL((k_points_sum<G1Cfg>), dim3(1), dim3(64), 0, (hipStream_t)stream, (const u32*)d_points, k,
+                       (u32*)d_out);
+  } else {
+#if defined(OZK_WITH_G2)
+    hipLaunchKernelGGL((k_points_sum<G2Cfg>), dim3(1), dim3(64), 0, (hipStream_t)stream, (const u32*)d_points, k,
+                       (u32*)d_out);
+#else
+    return fail(OZK_E_INVALID, "G2 not built");
+#endif
+  }
+  OZK_HIP(hipGetLastError());
+  return OZK_OK;
+}
+
+int ozk_gen_bases_dev(uint64_t seed, int32_t n, int32_t type, void* d_out_wire, void* stream) {
+  if (!d_out_wire || n <= 0) return fail(OZK_E_INVALID, "bad argument");
+  if (type != OZK_G1) return fail(OZK_E_INVALID, "only G1 synthetic bases are generated");
+  // generator (1, 2) (BN254aG1Parameters.java:23-24), wire format
+  u32 gen[16];
+  memset(gen, 0, sizeof(gen));
+  gen[0] = 1;
+  gen[8] = 2;
+  u32* d_gen = nullptr;
+  OZK_HIP(hipMalloc((void**)&d_gen, sizeof(gen)));
+  OZK_HIP(hipMemcpyAsync(d_gen, gen, sizeof(gen), hipMemcpyHostToDevice, (hipStream_t)stream));
+  hipLaunchKernelGGL((k_gen_bases<G1Cfg>), dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, seed, n,
+                     d_gen, (u32*)d_out_wire);
+  OZK_HIP(hipGetLastError());
+  OZK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  OZK_HIP(hipFree(d_gen));
+  return OZK_OK;
+}
+
+const char* ozk_last_error(void) { return err_buf(); }
+int ozk_version(void) { return 1; }
+int ozk_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,70 @@
+"""ctypes binding of libozk_hip.so (include/ozk.h).  No CPU path: if the library is
+missing or cannot be loaded, importing callers get a RuntimeError."""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libozk_hip.so")
+
+_lib = None
+
+c_u8p = ctypes.POINTER(ctypes.c_uint8)
+i32 = ctypes.c_int32
+vp = ctypes.c_void_p
+sz = ctypes.c_size_t
+
+_SIGS = {
+    "ozk_last_error": (ctypes.c_char_p, []),
+    "ozk_version": (ctypes.c_int, []),
+    "ozk_device_count": (ctypes.c_int, []),
+    "ozk_var_msm_host": (ctypes.c_int, [vp, vp, i32, i32, i32, vp]),
+    "ozk_var_double_msm_host": (ctypes.c_int, [vp, vp, vp, i32, i32, vp]),
+    "ozk_var_msm_workspace_bytes": (sz, [i32, i32]),
+    "ozk_var_msm_dev": (ctypes.c_int, [vp, vp, i32, i32, vp, vp, sz, vp]),
+    "ozk_gen_bases_dev": (ctypes.c_int, [ctypes.c_uint64, i32, i32, vp, vp]),
+    "ozk_points_sum_dev": (ctypes.c_int, [vp, i32, i32, vp, vp]),
+    "ozk_fixed_batch_msm_host": (ctypes.c_int, [i32, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp]),
+    "ozk_fixed_double_batch_msm_host": (ctypes.c_int, [i32] * 9 + [vp, vp, vp, i32, vp]),
+    "ozk_field_batch_mul_host": (ctypes.c_int, [vp, i32, i32, vp]),
+    "ozk_fixed_batch_msm_workspace_bytes": (sz, [i32, i32, i32, i32]),
+    "ozk_fixed_batch_msm_dev": (ctypes.c_int, [i32, i32, i32, vp, vp, i32, vp, vp, sz, vp]),
+    "ozk_field_batch_mul_dev": (ctypes.c_int, [vp, i32, vp, vp]),
+    "ozk_fft_host": (ctypes.c_int, [vp, i32, vp, i32, vp]),
+    "ozk_fft_workspace_bytes": (sz, [i32]),
+    "ozk_fft_dev": (ctypes.c_int, [vp, i32, vp, vp, vp, sz, vp]),
+}
+
+
+class OzkError(RuntimeError):
+    pass
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def load():
+    """Load libozk_hip.so; raise if absent (the product has no CPU fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OzkError(
+            "libozk_hip.so is not built (%s). Run `python -m octopuszk_amd.build`; "
+            "there is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    missing = [name for name in _SIGS if not hasattr(lib, name)]
+    if missing:
+        raise OzkError("libozk_hip.so lacks symbols declared in include/ozk.h: %s" % ", ".join(missing))
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().ozk_last_error()
+        raise OzkError("ozk call failed (%d): %s" % (rc, msg.decode() if msg else "?"))

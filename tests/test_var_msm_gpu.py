@@ -1,0 +1,82 @@
+"""GPU parity tests of VariableBaseMSM through the C ABI against the oracle (bit-exact on
+the affine-normalised point)."""
+import random
+
+import pytest
+
+from oracle import bn254 as o
+from oracle.javarand import JavaRandom
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_points(C, n, rng, affine=True):
+    pts = []
+    for _ in range(n):
+        P = C.mul(C.one, rng.randrange(1, 1 << 64))
+        pts.append(C.to_affine(P) if affine else P)
+    return pts
+
+
+def _run_g1(scalars, bases):
+    from octopuszk_amd import variable_base_msm as vb
+    raw = vb.variable_base_serial_msm_native_helper(vb.marshal_g1(bases), vb.marshal_scalars(scalars),
+                                                    len(scalars), 1, 0)
+    return raw
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 64, 257, 1023])
+def test_g1_small_vs_oracle(n):
+    rng = random.Random(100 + n)
+    bases = _rand_points(o.G1, n, rng)
+    scalars = [rng.randrange(o.R) for _ in range(n)]
+    want = o.G1.to_affine(o.pippenger_msm(o.G1, scalars, bases))
+    assert _run_g1(scalars, bases) == o.g1_out_le(want)
+
+
+def test_g1_toy_kat():
+    # SerialVariableBaseMSMTest.java:31-77 restated on BN254: (3,11,2,8).(5G,2G,7G,3G) = 75G
+    G = o.G1
+    bases = [G.to_affine(G.mul(G.one, k)) for k in (5, 2, 7, 3)]
+    want = G.to_affine(G.mul(G.one, 75))
+    assert _run_g1([3, 11, 2, 8], bases) == o.g1_out_le(want)
+
+
+def test_g1_edge_scalars_and_points():
+    G = o.G1
+    rng = random.Random(5)
+    bases = _rand_points(G, 40, rng)
+    bases[3] = G.zero                      # infinity among the bases
+    bases[4] = bases[5]                    # repeated base
+    bases[6] = G.negate(bases[7])          # P and -P
+    scalars = [rng.randrange(o.R) for _ in range(40)]
+    scalars[0] = 0
+    scalars[1] = 1
+    scalars[2] = o.R - 1
+    scalars[6] = scalars[7] = 12345        # P*s + (-P)*s = 0 inside one bucket
+    scalars[4] = scalars[5]
+    want = G.to_affine(o.naive_msm(G, scalars, bases))
+    assert _run_g1(scalars, bases) == o.g1_out_le(want)
+    # all-zero scalars -> infinity (0, 1, 0)
+    assert _run_g1([0] * 40, bases) == o.g1_out_le(G.zero)
+
+
+def test_g1_profiler_shaped_inputs():
+    # VariableBaseMSMProfiling.java:19-31: ONE base repeated, Fp.random scalars (64-bit or r-64-bit)
+    G = o.G1
+    n = 300
+    base = G.to_affine(G.mul(G.one, 987654321))
+    jr = JavaRandom(10)
+    scalars = [jr.next_long() % o.R for _ in range(n)]
+    want = G.to_affine(G.mul(base, sum(scalars) % o.R))
+    assert _run_g1(scalars, [base] * n) == o.g1_out_le(want)
+
+
+def test_g1_jacobian_inputs():
+    # reference-produced keys are un-normalised Jacobian points (Z != 1)
+    G = o.G1
+    rng = random.Random(9)
+    bases = _rand_points(G, 50, rng, affine=False)
+    scalars = [rng.randrange(o.R) for _ in range(50)]
+    want = G.to_affine(o.naive_msm(G, scalars, bases))
+    assert _run_g1(scalars, bases) == o.g1_out_le(want)
