@@ -72,6 +72,14 @@ int ozk_var_msm_dev(const void* d_bases, const void* d_scalars, int32_t n, int32
  * reduce(GroupT::add) of VariableBaseMSM.java:777-783 after the RCCL all-gather. */
 int ozk_points_sum_dev(const void* d_points, int32_t k, int32_t type, void* d_out, void* stream);
 
+/* Measurement hooks (bench.py): when enabled, ozk_var_msm_dev brackets its dominant kernel
+ * (the level-1 bucket accumulation, k_segreduce<.., true>) with HIP events on the launch
+ * stream; ozk_prof_dominant_kernel_ms returns the mean duration over the launches since
+ * ozk_prof_enable(1).  ozk_var_msm_plan reports the window size the library picks for n. */
+int ozk_prof_enable(int on);
+int ozk_prof_dominant_kernel_ms(double* avg_ms, int* launches);
+int ozk_var_msm_plan(int32_t n, int32_t* window_bits, int32_t* windows);
+
 /* Synthetic inputs for benchmarks / full-size tests (BASELINE.md config 2 generator):
  * writes n G1 bases P_i = k_i * G, k_i = splitmix64(seed + i) (k_i = 1 if that is 0), in the
  * wire-in format (affine, Z = 1).  Not part of the reference's surface. */

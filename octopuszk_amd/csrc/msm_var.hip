@@ -13,6 +13,18 @@
 
 namespace ozk {
 
+// Optional per-launch timing of the dominant kernel (level-1 segmented reduce) with HIP
+// events recorded on the stream it is launched on; bench.py reads the average after its
+// timed region (roofline.achieved).
+struct ProfState {
+  bool on = false;
+  int count = 0;
+  static constexpr int MAXP = 512;
+  hipEvent_t e0[MAXP], e1[MAXP];
+  bool created = false;
+};
+static ProfState g_prof;
+
 static MsmPlan make_plan(int n) {
   MsmPlan p;
   p.n = n;
@@ -110,9 +122,12 @@ static int var_msm_dev(const void* d_bases, const void* d_scalars, int n, void* 
                      p.c, L.sidx, L.sbid);
   // level 1 over the sorted entries
   size_t lanes = (L.cap + p.L1 - 1) / p.L1;
+  const bool prof = g_prof.on && g_prof.created && g_prof.count < ProfState::MAXP;
+  if (prof) hipEventRecord(g_prof.e0[g_prof.count], st);
   hipLaunchKernelGGL((k_segreduce<CV, true>), dim3((unsigned)((lanes + TB - 1) / TB)), dim3(TB), 0, st,
                      L.sbid, L.sidx, L.aff, L.total, 0, p.L1, L.buckets, L.slot_bid[0], L.slot_pts[0],
                      (int)lanes);
+  if (prof) hipEventRecord(g_prof.e1[g_prof.count++], st);
   // levels >= 2 over the partial slots, ping-pong, until a single lane has seen everything
   size_t n_in = 2 * lanes;
   int cur = 0;
@@ -275,6 +290,41 @@ int ozk_gen_bases_dev(uint64_t seed, int32_t n, int32_t type, void* d_out_wire, 
   OZK_HIP(hipGetLastError());
   OZK_HIP(hipStreamSynchronize((hipStream_t)stream));
   OZK_HIP(hipFree(d_gen));
+  return OZK_OK;
+}
+
+int ozk_prof_enable(int on) {
+  if (on && !g_prof.created) {
+    for (int i = 0; i < ProfState::MAXP; i++) {
+      OZK_HIP(hipEventCreate(&g_prof.e0[i]));
+      OZK_HIP(hipEventCreate(&g_prof.e1[i]));
+    }
+    g_prof.created = true;
+  }
+  g_prof.on = on != 0;
+  g_prof.count = 0;
+  return OZK_OK;
+}
+
+int ozk_prof_dominant_kernel_ms(double* avg_ms, int* launches) {
+  if (!avg_ms || !launches) return fail(OZK_E_INVALID, "null pointer argument");
+  double tot = 0;
+  for (int i = 0; i < g_prof.count; i++) {
+    float ms = 0;
+    OZK_HIP(hipEventSynchronize(g_prof.e1[i]));
+    OZK_HIP(hipEventElapsedTime(&ms, g_prof.e0[i], g_prof.e1[i]));
+    tot += ms;
+  }
+  *launches = g_prof.count;
+  *avg_ms = g_prof.count ? tot / g_prof.count : 0.0;
+  return OZK_OK;
+}
+
+int ozk_var_msm_plan(int32_t n, int32_t* window_bits, int32_t* windows) {
+  if (n <= 0 || !window_bits || !windows) return fail(OZK_E_INVALID, "bad argument");
+  const MsmPlan p = make_plan(n);
+  *window_bits = p.c;
+  *windows = p.W;
   return OZK_OK;
 }
 

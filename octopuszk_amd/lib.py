@@ -21,6 +21,9 @@ _SIGS = {
     "ozk_var_double_msm_host": (ctypes.c_int, [vp, vp, vp, i32, i32, vp]),
     "ozk_var_msm_workspace_bytes": (sz, [i32, i32]),
     "ozk_var_msm_dev": (ctypes.c_int, [vp, vp, i32, i32, vp, vp, sz, vp]),
+    "ozk_prof_enable": (ctypes.c_int, [ctypes.c_int]),
+    "ozk_prof_dominant_kernel_ms": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
+    "ozk_var_msm_plan": (ctypes.c_int, [i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]),
     "ozk_gen_bases_dev": (ctypes.c_int, [ctypes.c_uint64, i32, i32, vp, vp]),
     "ozk_points_sum_dev": (ctypes.c_int, [vp, i32, i32, vp, vp]),
     "ozk_fixed_batch_msm_host": (ctypes.c_int, [i32, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp]),
@@ -52,6 +55,14 @@ def load():
         raise OzkError(
             "libozk_hip.so is not built (%s). Run `python -m octopuszk_amd.build`; "
             "there is no CPU fallback." % LIB_PATH)
+    # Device pointers handed over by torch (bench.py, torch.distributed ranks) are only valid
+    # in the HIP runtime instance torch itself loaded, so when torch is installed it must be
+    # imported BEFORE libozk_hip.so pulls in libamdhip64 (else two runtimes coexist and the
+    # second one reports "no ROCm-capable device").  A JVM loads the library without torch.
+    try:
+        import torch  # noqa: F401  (plumbing only)
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     missing = [name for name in _SIGS if not hasattr(lib, name)]
     if missing:
