@@ -1,0 +1,184 @@
+// Fq2 = Fq[u]/(u^2 + 1) for BN254 G2, on top of fp29.cuh.  One Fq2 element per lane.
+//
+// Restates algebra/fields/Fp2.java:44-107 (Karatsuba mul :59-72, complex squaring
+// :94-103, inverse :105-115) with non-residue -1 applied as a subtraction — the
+// reference's CUDA multiplies by q-1 with a full mul+rem (VariableBaseMSM.cu:229-232).
+//
+// Bounds: Fe2<B> has both components < B*p/16.  mul / sqr reduce their inputs to < 2p
+// when the Karatsuba sums would break the Montgomery precondition and always return
+// components < 2p, so the generic group law of ec.cuh type-checks unchanged.
+#pragma once
+#include "curve.cuh"
+
+namespace ozk {
+
+template <int B>
+struct Fe2 {
+  Fe<FqParams, B> c0, c1;
+  OZK_HD Fe2() {}
+  template <int B2, class = std::enable_if_t<(B2 <= B)>>
+  OZK_HD Fe2(const Fe2<B2>& o) : c0(o.c0), c1(o.c1) {}
+};
+
+template <int B>
+OZK_HD Fe2<1> el_zero(const Fe2<B>&) {
+  Fe2<1> r;
+  r.c0 = fe_zero<FqParams>();
+  r.c1 = fe_zero<FqParams>();
+  return r;
+}
+template <int B>
+OZK_HD Fe2<16> el_one(const Fe2<B>&) {
+  Fe2<16> r;
+  r.c0 = fe_one<FqParams>();
+  r.c1 = Fe<FqParams, 16>(fe_zero<FqParams>());
+  return r;
+}
+
+template <int B1, int B2>
+OZK_HD auto add(const Fe2<B1>& a, const Fe2<B2>& b) {
+  Fe2<B1 + B2> r;
+  r.c0 = add(a.c0, b.c0);
+  r.c1 = add(a.c1, b.c1);
+  return r;
+}
+template <int B1>
+OZK_HD auto dbl(const Fe2<B1>& a) {
+  Fe2<2 * B1> r;
+  r.c0 = dbl(a.c0);
+  r.c1 = dbl(a.c1);
+  return r;
+}
+template <int B1, int B2>
+OZK_HD auto sub(const Fe2<B1>& a, const Fe2<B2>& b) {
+  Fe2<B1 + 16 * (B2 / 16 + 1)> r;
+  r.c0 = sub(a.c0, b.c0);
+  r.c1 = sub(a.c1, b.c1);
+  return r;
+}
+template <int B2>
+OZK_HD auto neg(const Fe2<B2>& b) {
+  Fe2<16 * (B2 / 16 + 1)> r;
+  r.c0 = neg(b.c0);
+  r.c1 = neg(b.c1);
+  return r;
+}
+template <int TB, int B>
+OZK_HD auto reduce_to(const Fe2<B>& a) {
+  if constexpr (B <= TB) {
+    return a;
+  } else {
+    auto x = reduce_to<TB>(a.c0);
+    auto y = reduce_to<TB>(a.c1);
+    using T = decltype(x);
+    Fe2<TB> r;
+    r.c0 = Fe<FqParams, TB>(x);
+    r.c1 = Fe<FqParams, TB>(y);
+    (void)sizeof(T);
+    return r;
+  }
+}
+template <int B>
+OZK_HD Fe2<16> canonical(const Fe2<B>& a) {
+  Fe2<16> r;
+  r.c0 = canonical(a.c0);
+  r.c1 = canonical(a.c1);
+  return r;
+}
+template <int B>
+OZK_HD bool is_zero(const Fe2<B>& a) {  // Fp2.java:78-80
+  return is_zero(a.c0) && is_zero(a.c1);
+}
+
+constexpr bool kara_ok(int B1, int B2) { return 4LL * B1 * B2 <= (long long)MONT_SLACK * 256; }
+
+// (a0 + a1 u)(b0 + b1 u) = (a0b0 - a1b1) + ((a0+a1)(b0+b1) - a0b0 - a1b1) u   (Fp2.java:59-72)
+template <int B1, int B2>
+OZK_HD Fe2<32> mul(const Fe2<B1>& a_in, const Fe2<B2>& b_in) {
+  if constexpr (!kara_ok(B1, B2)) {
+    return mul(reduce_to<(B1 > 32 ? 32 : B1)>(a_in), reduce_to<(B2 > 32 ? 32 : B2)>(b_in));
+  } else {
+    const auto v0 = mul(a_in.c0, b_in.c0);
+    const auto v1 = mul(a_in.c1, b_in.c1);
+    const auto s = mul(add(a_in.c0, a_in.c1), add(b_in.c0, b_in.c1));
+    Fe2<32> r;
+    r.c0 = Fe<FqParams, 32>(reduce_to<32>(sub(v0, v1)));
+    r.c1 = Fe<FqParams, 32>(reduce_to<32>(sub(s, add(v0, v1))));
+    return r;
+  }
+}
+// (a0 + a1 u)^2 = (a0+a1)(a0-a1) + 2 a0 a1 u        (Fp2.java:94-103 with nonresidue = -1)
+template <int B1>
+OZK_HD Fe2<32> sqr(const Fe2<B1>& a_in) {
+  if constexpr (B1 > 32) {
+    return sqr(reduce_to<32>(a_in));
+  } else {
+    const auto t = mul(a_in.c0, a_in.c1);
+    const auto d = mul(add(a_in.c0, a_in.c1), sub(a_in.c0, a_in.c1));
+    Fe2<32> r;
+    r.c0 = Fe<FqParams, 32>(reduce_to<32>(d));
+    r.c1 = Fe<FqParams, 32>(reduce_to<32>(dbl(t)));
+    return r;
+  }
+}
+// Fp2.java:105-115 (Algorithm 8): (a0 - a1 u) / (a0^2 + a1^2)
+template <int B>
+OZK_HD Fe2<32> inv(const Fe2<B>& a_in) {
+  const auto a = reduce_to<32>(a_in);
+  const auto t = add(sqr(a.c0), sqr(a.c1));
+  const auto ti = inv(t);
+  Fe2<32> r;
+  r.c0 = Fe<FqParams, 32>(mul(a.c0, ti));
+  r.c1 = Fe<FqParams, 32>(reduce_to<32>(neg(mul(a.c1, ti))));
+  return r;
+}
+
+template <int B>
+struct ElemTraits<Fe2<B>> {
+  using E1 = ElemTraits<Fe<FqParams, B>>;
+  static constexpr int WORDS = 16;
+  static OZK_HD Fe2<B> load(const u32* p) {
+    Fe2<B> r;
+    r.c0 = E1::load(p);
+    r.c1 = E1::load(p + 8);
+    return r;
+  }
+  static OZK_HD void store(const Fe2<B>& e, u32* p) {
+    E1::store(e.c0, p);
+    E1::store(e.c1, p + 8);
+  }
+  static OZK_HD Fe2<B> from_wire(const u32* p) {
+    Fe2<B> r;
+    r.c0 = E1::from_wire(p);
+    r.c1 = E1::from_wire(p + 8);
+    return r;
+  }
+  static OZK_HD void to_wire(const Fe2<B>& e, u32* p) {
+    E1::to_wire(e.c0, p);
+    E1::to_wire(e.c1, p + 8);
+  }
+  // c0 (64 B) | c1 (64 B), VariableBaseMSM.cu:1781-1784 order Xa|Xb
+  static OZK_HD void to_wire_out(const Fe2<B>& e, u32* p) {
+    E1::to_wire_out(e.c0, p);
+    E1::to_wire_out(e.c1, p + 16);
+  }
+  static OZK_HD Fe2<B> from_wire_out(const u32* p) {
+    Fe2<B> r;
+    r.c0 = E1::from_wire(p);
+    r.c1 = E1::from_wire(p + 16);
+    return r;
+  }
+  static OZK_HD bool wire_is_zero(const u32* p) { return E1::wire_is_zero(p) && E1::wire_is_zero(p + 8); }
+  static OZK_HD bool wire_is_one(const u32* p) { return E1::wire_is_one(p) && E1::wire_is_zero(p + 8); }
+};
+
+// G2 over Fq2.  Loop-carried bounds: mul / sqr return < 2p, so the madd outputs are
+// X3 = sqr - (J + 2V) < 2p + 7p, Y3 < 2p + 5p, Z3 < 2p + 5p.
+struct G2Cfg {
+  using EX = Fe2<144>;
+  using EY = Fe2<112>;
+  using EZ = Fe2<112>;
+  using EA = Fe2<17>;
+};
+
+}  // namespace ozk

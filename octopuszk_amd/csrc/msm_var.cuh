@@ -372,7 +372,7 @@ __device__ __forceinline__ u32 opaque_zero() {
 }
 
 template <class CV>
-__global__ void k_finalize(const u32* __restrict__ A_w, int W, int c, u32* __restrict__ out) {
+__global__ void __launch_bounds__(64) k_finalize(const u32* __restrict__ A_w, int W, int c, u32* __restrict__ out) {
   using IO = CurveIO<CV>;
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   A_w += opaque_zero();
@@ -386,7 +386,7 @@ __global__ void k_finalize(const u32* __restrict__ A_w, int W, int c, u32* __res
 
 // sum of k points given in wire-out format (affine or (0,1,0)); used for the multi-GPU reduce
 template <class CV>
-__global__ void k_points_sum(const u32* __restrict__ pts, int k, u32* __restrict__ out) {
+__global__ void __launch_bounds__(64) k_points_sum(const u32* __restrict__ pts, int k, u32* __restrict__ out) {
   using EA = typename CV::EA;
   using ET = ElemTraits<EA>;
   constexpr int OW = 2 * ET::WORDS;

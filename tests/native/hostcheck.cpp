@@ -64,3 +64,37 @@ extern "C" void hc_g1_op(int op, const u32* pw, const u32* qw, int k, u32* out) 
   }
   store_jac(r, out);
 }
+
+// ---------------------------------------------------------------- Fq2 / G2
+#include "../../octopuszk_amd/csrc/fq2.cuh"
+extern "C" void hc_fq2_op(int op, const u32* a, const u32* b, u32* out) {  // 16 words each: c0|c1
+  using ET = ElemTraits<Fe2<17>>;
+  Fe2<17> x = ET::from_wire(a), y = ET::from_wire(b);
+  switch (op) {
+    case 0: ElemTraits<Fe2<32>>::to_wire(mul(x, y), out); break;
+    case 1: ElemTraits<Fe2<32>>::to_wire(sqr(x), out); break;
+    case 2: ElemTraits<Fe2<34>>::to_wire(add(x, y), out); break;
+    case 3: ElemTraits<Fe2<49>>::to_wire(sub(x, y), out); break;
+    case 4: ElemTraits<Fe2<32>>::to_wire(inv(x), out); break;
+    case 5: { auto big = sub(dbl(dbl(x)), y); ElemTraits<Fe2<32>>::to_wire(mul(big, big), out); break; }
+    default: break;
+  }
+}
+typedef G2Cfg J2;
+extern "C" void hc_g2_op(int op, const u32* pw, const u32* qw, int k, u32* out) {  // 48 words per point
+  using IO = CurveIO<J2>;
+  Jac<J2> p = IO::jac_from_wire(pw), q = IO::jac_from_wire(qw), r;
+  Aff<J2::EA> qa; qa.x = J2::EA(reduce_to<17>(q.X)); qa.y = J2::EA(reduce_to<17>(q.Y));
+  switch (op) {
+    case 0: r = jac_add(p, q); break;
+    case 1: r = jac_dbl(p); break;
+    case 2: r = jac_madd(p, qa); break;
+    case 3: r = p; for (int i = 0; i < k; i++) r = jac_madd(r, qa); break;
+    case 4: r = p; for (int i = 0; i < k; i++) r = jac_add(r, q); break;
+    case 5: r = p; for (int i = 0; i < k; i++) r = jac_dbl(r); break;
+    default: r = p;
+  }
+  ElemTraits<J2::EX>::to_wire(r.X, out);
+  ElemTraits<J2::EY>::to_wire(r.Y, out + 16);
+  ElemTraits<J2::EZ>::to_wire(r.Z, out + 32);
+}

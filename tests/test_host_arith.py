@@ -114,3 +114,63 @@ def test_g1_group_law(hc):
     # CurvesTest.java:27-82 identities on the HIP group law
     a = pts[3]
     assert G.equals(g1_op(hc, 0, G.mul(a, 76749407), G.mul(a, 44410867)), G.mul(a, 121160274))
+
+
+def _w2(v):
+    return (ctypes.c_uint32 * 16)(*[(c >> (32 * i)) & 0xffffffff for c in v for i in range(8)])
+
+
+def fq2_op(hc, op, a, b=(0, 0)):
+    out = (ctypes.c_uint32 * 16)()
+    hc.hc_fq2_op(op, _w2(a), _w2(b), out)
+    return (_r(out[0:8]), _r(out[8:16]))
+
+
+def test_fq2_ops(hc):
+    F = o.Fq2Ops
+    rng = random.Random(21)
+    vals = [(0, 0), (1, 0), (0, 1), (o.Q - 1, o.Q - 1), (o.Q - 1, 0), (5, o.Q - 2)]
+    vals += [(rng.randrange(o.Q), rng.randrange(o.Q)) for _ in range(60)]
+    for i, a in enumerate(vals):
+        b = vals[(i * 5 + 1) % len(vals)]
+        assert fq2_op(hc, 0, a, b) == F.mul(a, b)
+        assert fq2_op(hc, 1, a) == F.sqr(a)
+        assert fq2_op(hc, 2, a, b) == F.add(a, b)
+        assert fq2_op(hc, 3, a, b) == F.sub(a, b)
+        big = F.sub(F.add(F.add(a, a), F.add(a, a)), b)
+        assert fq2_op(hc, 5, a, b) == F.mul(big, big)
+        if a != (0, 0):
+            assert fq2_op(hc, 4, a) == F.inv(a)
+
+
+def _pw2(P):
+    return (ctypes.c_uint32 * 48)(*[(c >> (32 * i)) & 0xffffffff for co in P for c in co for i in range(8)])
+
+
+def g2_op(hc, op, P, Qp, k=0):
+    out = (ctypes.c_uint32 * 48)()
+    hc.hc_g2_op(op, _pw2(P), _pw2(Qp), k, out)
+    v = [_r(out[8 * i:8 * i + 8]) for i in range(6)]
+    return ((v[0], v[1]), (v[2], v[3]), (v[4], v[5]))
+
+
+def test_g2_group_law(hc):
+    G = o.G2
+    rng = random.Random(12)
+    pts = [G.mul(G.one, rng.randrange(1, o.R)) for _ in range(6)]
+    aff = [G.to_affine(P) for P in pts]
+    for i in range(len(pts)):
+        P, Qa = pts[i], aff[(i + 1) % len(pts)]
+        assert G.equals(g2_op(hc, 0, P, pts[(i + 1) % len(pts)]), G.add(P, Qa))
+        assert G.equals(g2_op(hc, 1, P, P), G.twice(P))
+        assert G.equals(g2_op(hc, 2, P, Qa), G.add(P, Qa))
+    P, Pa = pts[0], aff[0]
+    assert G.equals(g2_op(hc, 0, P, Pa), G.twice(P))
+    assert G.equals(g2_op(hc, 2, P, Pa), G.twice(P))
+    assert G.is_zero(g2_op(hc, 0, P, G.negate(Pa)))
+    assert G.is_zero(g2_op(hc, 2, P, G.negate(Pa)))
+    assert G.equals(g2_op(hc, 0, G.zero, Pa), P)
+    assert G.equals(g2_op(hc, 2, G.zero, Pa), P)
+    assert G.equals(g2_op(hc, 3, P, aff[1], 100), G.add(P, G.mul(aff[1], 100)))
+    assert G.equals(g2_op(hc, 4, P, pts[2], 50), G.add(P, G.mul(pts[2], 50)))
+    assert G.equals(g2_op(hc, 5, P, P, 40), G.mul(P, 1 << 40))

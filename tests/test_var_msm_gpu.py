@@ -80,3 +80,63 @@ def test_g1_jacobian_inputs():
     scalars = [rng.randrange(o.R) for _ in range(50)]
     want = G.to_affine(o.naive_msm(G, scalars, bases))
     assert _run_g1(scalars, bases) == o.g1_out_le(want)
+
+
+# ---------------------------------------------------------------- G2 and the double MSM
+def _run_g2(scalars, bases):
+    from octopuszk_amd import variable_base_msm as vb
+    return vb.variable_base_serial_msm_native_helper(vb.marshal_g2(bases), vb.marshal_scalars(scalars),
+                                                     len(scalars), 2, 0)
+
+
+@pytest.mark.parametrize("n", [1, 3, 64, 300])
+def test_g2_small_vs_oracle(n):
+    rng = random.Random(200 + n)
+    bases = _rand_points(o.G2, n, rng)
+    scalars = [rng.randrange(o.R) for _ in range(n)]
+    want = o.G2.to_affine(o.pippenger_msm(o.G2, scalars, bases))
+    assert _run_g2(scalars, bases) == o.g2_out_le(want)
+
+
+def test_g2_edge_cases():
+    G = o.G2
+    rng = random.Random(6)
+    bases = _rand_points(G, 24, rng, affine=False)   # Jacobian (Z != 1) inputs
+    bases[3] = G.zero                                 # fork quirk: (0,0,0) encodes infinity
+    bases[4] = bases[5]
+    bases[6] = G.negate(bases[7])
+    scalars = [rng.randrange(o.R) for _ in range(24)]
+    scalars[0], scalars[1], scalars[2] = 0, 1, o.R - 1
+    scalars[6] = scalars[7] = 999
+    want = G.to_affine(o.naive_msm(G, scalars, bases))
+    assert _run_g2(scalars, bases) == o.g2_out_le(want)
+    assert _run_g2([0] * 24, bases) == o.g2_out_le(G.zero_affine)
+
+
+def test_double_msm():
+    # variableBaseDoubleMSMNativeHelper: 576 B = G1 (192) || G2 (384)  (VariableBaseMSM.cu:1781-1784)
+    from octopuszk_amd import variable_base_msm as vb
+    rng = random.Random(8)
+    n = 40
+    b1 = _rand_points(o.G1, n, rng)
+    b2 = _rand_points(o.G2, n, rng)
+    sc = [rng.randrange(o.R) for _ in range(n)]
+    raw = vb.variable_base_double_msm_native_helper(vb.marshal_g1(b1), vb.marshal_g2(b2), vb.marshal_scalars(sc), n, 0)
+    assert raw[:192] == o.g1_out_le(o.G1.to_affine(o.naive_msm(o.G1, sc, b1)))
+    assert raw[192:] == o.g2_out_le(o.G2.to_affine(o.naive_msm(o.G2, sc, b2)))
+
+
+def test_serial_msm_mirror_chunks_and_sums():
+    # VariableBaseMSM.serialMSM (VariableBaseMSM.java:199-338): chunk results summed with the group add
+    from octopuszk_amd import variable_base_msm as vb
+    rng = random.Random(13)
+    n = 50
+    bases = _rand_points(o.G1, n, rng)
+    sc = [rng.randrange(o.R) for _ in range(n)]
+    old = vb.G1_ITERATION_BATCH
+    vb.G1_ITERATION_BATCH = 16  # force 4 chunks
+    try:
+        got = vb.serial_msm(sc, bases, o.G1.add, o.G1.zero, is_g1=True)
+    finally:
+        vb.G1_ITERATION_BATCH = old
+    assert o.G1.equals(got, o.naive_msm(o.G1, sc, bases))
