@@ -1,11 +1,329 @@
-// placeholder until the fixed-base kernels land (this round)
+// Fixed-base batch MSM (G1 / G2) and the Fr vector-times-scalar product: kernels, host
+// driver and C ABI (include/ozk.h).
+//
+// Replaces fixed_batch_MSMG1 / G2, fixed_double_batch_MSM, field_MSM and their kernels
+// (algebra_msm_FixedBaseMSM.cu:750-1266) and the three JNI natives of
+// algebra.msm.FixedBaseMSM (.cu:1276-1558).  Value computed per scalar, as
+// FixedBaseMSM.serialMSM (FixedBaseMSM.java:141-167) with the table of
+// getWindowTable (FixedBaseMSM.java:71-99):
+//     result_i = sum_{w < outerc} digit_w(s_i) * 2^(w*windowSize) * B
+// Outputs are affine-normalised (so keys produced here take the Z == 1 fast path of the
+// variable-base MSM) and written in the reference's layout: 64-byte BIG-endian
+// coordinates (FixedBaseMSM.cu:783-787).
+//
+// Device pipeline:
+//   k_fb_chain    D[j] = 2^j * B, j < outerc*windowSize           (one serial doubling chain)
+//   k_fb_level k  table[w][2^k + j] = table[w][j] + D[w*ws + k]   (windowSize launches, all
+//                 windows and all j in parallel; the reference re-doubles per window and adds
+//                 popcount(i) points per entry, FixedBaseMSM.cu:851-992)
+//   k_fb_main     per scalar: gather-add one table entry per window (Jacobian)
+//   k_fb_norm     per lane a batch of results: one shared inversion (Montgomery's trick),
+//                 big-endian stores
+#include "fq2.cuh"
 #include "ozk_common.h"
-using namespace ozk;
-extern "C" {
-int ozk_fixed_batch_msm_host(int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, const uint8_t*, const uint8_t*, int32_t, int32_t, uint8_t*) { return fail(OZK_E_INTERNAL, "fixed-base MSM not implemented yet"); }
-int ozk_fixed_double_batch_msm_host(int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, const uint8_t*, const uint8_t*, const uint8_t*, int32_t, uint8_t*) { return fail(OZK_E_INTERNAL, "fixed-base MSM not implemented yet"); }
-int ozk_field_batch_mul_host(const uint8_t*, int32_t, int32_t, uint8_t*) { return fail(OZK_E_INTERNAL, "not implemented yet"); }
-size_t ozk_fixed_batch_msm_workspace_bytes(int32_t, int32_t, int32_t, int32_t) { return 0; }
-int ozk_fixed_batch_msm_dev(int32_t, int32_t, int32_t, const void*, const void*, int32_t, void*, void*, size_t, void*) { return fail(OZK_E_INTERNAL, "not implemented yet"); }
-int ozk_field_batch_mul_dev(const void*, int32_t, void*, void*) { return fail(OZK_E_INTERNAL, "not implemented yet"); }
+
+namespace ozk {
+
+template <class CV>
+__global__ void __launch_bounds__(64) k_fb_chain(const u32* __restrict__ base_wire, int total, u32* __restrict__ D) {
+  using IO = CurveIO<CV>;
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  base_wire += opaque_zero();
+  Jac<CV> p = IO::jac_from_wire(base_wire);
+  for (int j = 0; j < total; j++) {
+    IO::store_jac(p, D + (size_t)j * IO::JAC_WORDS);
+    p = jac_dbl(p);
+  }
 }
+
+// level k: entries [2^k, 2^(k+1)) of every window.  table[w][0] = infinity (zeroed).
+template <class CV>
+__global__ void __launch_bounds__(256) k_fb_level(u32* __restrict__ table, const u32* __restrict__ D, int outerc,
+                                                  int ws, int k) {
+  using IO = CurveIO<CV>;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int half = 1 << k;
+  if (t >= outerc * half) return;
+  const int w = t >> k, j = t & (half - 1);
+  const size_t row = (size_t)w << ws;
+  const Jac<CV> add = IO::load_jac(D + (size_t)(w * ws + k) * IO::JAC_WORDS);
+  Jac<CV> r;
+  if (j == 0) {
+    r = add;
+  } else {
+    r = jac_add(IO::load_jac(table + (row + j) * IO::JAC_WORDS), add);
+  }
+  IO::store_jac(r, table + (row + half + j) * IO::JAC_WORDS);
+}
+
+template <class CV>
+__global__ void __launch_bounds__(256) k_fb_main(const u32* __restrict__ scalars, const u32* __restrict__ table,
+                                                 int n, int outerc, int ws, u32* __restrict__ jac_out) {
+  using IO = CurveIO<CV>;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 s[8];
+  const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
+  const uint4 a = sp[0], b = sp[1];
+  s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w;
+  s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+  Jac<CV> acc = jac_infinity<CV>();
+  for (int w = 0; w < outerc; w++) {
+    // digit = bits [w*ws, w*ws + ws) (testBit loop, FixedBaseMSM.java:153-159); ws may exceed 16
+    u32 d = 0;
+    const int bit = w * ws;
+    if (bit < 256) {
+      const int wi = bit >> 5, sh = bit & 31;
+      unsigned long long v = s[wi];
+      if (wi + 1 < 8) v |= (unsigned long long)s[wi + 1] << 32;
+      d = (u32)(v >> sh) & ((1u << ws) - 1u);
+      // ws <= 22 and sh <= 31: two words always suffice
+    }
+    if (d != 0) acc = jac_add(acc, IO::load_jac(table + (((size_t)w << ws) + d) * IO::JAC_WORDS));
+  }
+  IO::store_jac(acc, jac_out + (size_t)i * IO::JAC_WORDS);
+}
+
+// 64-byte big-endian store of one Fq value: 8 zero words, then the value's words reversed
+// and byte-swapped (FixedBaseMSM.cu:740-748 swap_helper layout)
+template <class P, int B>
+__device__ __forceinline__ void store_be64(const Fe<P, B>& e, u32* p) {
+  u32 w[8];
+  from_mont(e, w);
+#pragma unroll
+  for (int i = 0; i < 8; i++) p[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) p[8 + i] = __builtin_bswap32(w[7 - i]);
+}
+template <int B>
+__device__ __forceinline__ void store_be_coord(const Fe<FqParams, B>& e, u32* p) { store_be64(e, p); }
+template <int B>
+__device__ __forceinline__ void store_be_coord(const Fe2<B>& e, u32* p) {
+  store_be64(e.c0, p);
+  store_be64(e.c1, p + 16);
+}
+
+constexpr int FB_BATCH = 8;
+// lane t normalises results [t*FB_BATCH, ...): prefix products of Z, one inversion, back-substitution.
+// out element i is at out + i*out_stride_words (+ coordinate offsets).
+template <class CV>
+__global__ void __launch_bounds__(256) k_fb_norm(const u32* __restrict__ jac, int n, u32* __restrict__ out,
+                                                 int out_stride_words) {
+  using IO = CurveIO<CV>;
+  using EA = typename CV::EA;
+  using ET = ElemTraits<EA>;
+  using EZ32 = decltype(reduce_to<32>(typename CV::EZ()));
+  constexpr int OW = 2 * ET::WORDS;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lo = t * FB_BATCH;
+  if (lo >= n) return;
+  const int cnt = (n - lo < FB_BATCH) ? (n - lo) : FB_BATCH;
+  // prefix[k] = product of the non-zero Z_0..Z_k
+  EZ32 prefix[FB_BATCH];
+  EZ32 run = EZ32(el_one(prefix[0]));
+#pragma unroll
+  for (int k = 0; k < FB_BATCH; k++) {
+    if (k < cnt) {
+      const auto Z = reduce_to<32>(ElemTraits<typename CV::EZ>::load(jac + (size_t)(lo + k) * IO::JAC_WORDS + 2 * IO::CW));
+      if (!is_zero(Z)) run = EZ32(mul(run, Z));
+    }
+    prefix[k] = run;
+  }
+  EZ32 invrun = EZ32(inv(run));
+#pragma unroll
+  for (int k = FB_BATCH - 1; k >= 0; k--) {
+    if (k < cnt) {
+      const Jac<CV> p = IO::load_jac(jac + (size_t)(lo + k) * IO::JAC_WORDS);
+      u32* o = out + (size_t)(lo + k) * out_stride_words;
+      const auto Z = reduce_to<32>(p.Z);
+      if (is_zero(Z)) {  // (0, 1, 0), BNG1.java:163-166
+        store_be_coord(EA(el_zero(p.X)), o);
+        store_be_coord(EA(el_one(p.X)), o + OW);
+        store_be_coord(EA(el_zero(p.X)), o + 2 * OW);
+      } else {
+        // 1/Z_k = invrun * prefix[k-1];  invrun <- invrun * Z_k
+        EZ32 zi = invrun;
+        if (k > 0) zi = EZ32(mul(invrun, prefix[k - 1]));
+        invrun = EZ32(mul(invrun, Z));
+        const auto zi2 = sqr(zi);
+        store_be_coord(EA(reduce_to<17>(mul(p.X, zi2))), o);
+        store_be_coord(EA(reduce_to<17>(mul(p.Y, mul(zi2, zi)))), o + OW);
+        store_be_coord(EA(el_one(p.X)), o + 2 * OW);
+      }
+    }
+  }
+}
+
+// x_i * b mod r, 64-byte big-endian out (field_MSM, FixedBaseMSM.cu:1241-1266)
+__global__ void __launch_bounds__(256) k_field_mul(const u32* __restrict__ in, int n, u32* __restrict__ out) {
+  using ET = ElemTraits<Fe<FrParams, 17>>;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const auto b = ET::from_wire(in + (size_t)n * 8);
+  const auto x = ET::from_wire(in + (size_t)i * 8);
+  store_be64(mul(x, b), out + (size_t)i * 16);
+}
+
+struct FbLayout {
+  u32 *D, *table, *jac;
+  size_t bytes;
+};
+template <class CV>
+static FbLayout fb_layout(int outerc, int ws, int n, void* wsp, size_t wsb) {
+  using IO = CurveIO<CV>;
+  FbLayout L;
+  Bump b(wsp, wsb);
+  L.D = b.take<u32>((size_t)outerc * ws * IO::JAC_WORDS);
+  L.table = b.take<u32>(((size_t)outerc << ws) * IO::JAC_WORDS);
+  L.jac = b.take<u32>((size_t)n * IO::JAC_WORDS);
+  b.take<u32>(64);
+  L.bytes = b.off;
+  return L;
+}
+
+static int fb_check_args(int outerc, int ws, int n) {
+  if (n <= 0 || n > (1 << 24)) return fail(OZK_E_INVALID, "batch_size %d out of range [1, 2^24]", n);
+  if (ws < 1 || ws > 22) return fail(OZK_E_INVALID, "windowSize %d out of range [1, 22]", ws);
+  if (outerc < 1 || (long long)outerc * ws > 512) return fail(OZK_E_INVALID, "outerc %d out of range", outerc);
+  return OZK_OK;
+}
+
+template <class CV>
+static int fixed_batch_dev(int outerc, int ws, int n, const void* d_base, const void* d_scalars, void* d_out,
+                           int out_stride_words, void* wsp, size_t wsb, hipStream_t st) {
+  using IO = CurveIO<CV>;
+  const FbLayout L = fb_layout<CV>(outerc, ws, n, wsp, wsb);
+  if (L.bytes > wsb) return fail(OZK_E_INVALID, "workspace too small: need %zu bytes, got %zu", L.bytes, wsb);
+  const int TB = 256;
+  hipLaunchKernelGGL((k_fb_chain<CV>), dim3(1), dim3(64), 0, st, (const u32*)d_base, outerc * ws, L.D);
+  // entry 0 of every window is infinity: clear those records (all-zero Jacobian has Z = 0)
+  OZK_HIP(hipMemset2DAsync(L.table, ((size_t)1 << ws) * IO::JAC_WORDS * 4, 0, IO::JAC_WORDS * 4, outerc, st));
+  for (int k = 0; k < ws; k++) {
+    const int tot = outerc << k;
+    hipLaunchKernelGGL((k_fb_level<CV>), dim3((tot + TB - 1) / TB), dim3(TB), 0, st, L.table, L.D, outerc, ws, k);
+  }
+  hipLaunchKernelGGL((k_fb_main<CV>), dim3((n + TB - 1) / TB), dim3(TB), 0, st, (const u32*)d_scalars, L.table, n,
+                     outerc, ws, L.jac);
+  const int lanes = (n + FB_BATCH - 1) / FB_BATCH;
+  hipLaunchKernelGGL((k_fb_norm<CV>), dim3((lanes + TB - 1) / TB), dim3(TB), 0, st, L.jac, n, (u32*)d_out,
+                     out_stride_words);
+  OZK_HIP(hipGetLastError());
+  return OZK_OK;
+}
+
+// RAII-less helper for the host variants
+struct DevBuf {
+  uint8_t* p = nullptr;
+  hipStream_t st = nullptr;
+  ~DevBuf() {
+    if (p) hipFree(p);
+    if (st) hipStreamDestroy(st);
+  }
+};
+
+}  // namespace ozk
+
+using namespace ozk;
+
+extern "C" {
+
+size_t ozk_fixed_batch_msm_workspace_bytes(int32_t outerc, int32_t ws, int32_t n, int32_t bn_type) {
+  if (fb_check_args(outerc, ws, n)) return 0;
+  return bn_type == OZK_G1 ? fb_layout<G1Cfg>(outerc, ws, n, nullptr, 0).bytes
+                           : fb_layout<G2Cfg>(outerc, ws, n, nullptr, 0).bytes;
+}
+
+int ozk_fixed_batch_msm_dev(int32_t outerc, int32_t ws, int32_t n, const void* d_base, const void* d_scalars,
+                            int32_t bn_type, void* d_out, void* d_workspace, size_t workspace_bytes, void* stream) {
+  if (!d_base || !d_scalars || !d_out || !d_workspace) return fail(OZK_E_INVALID, "null pointer argument");
+  int rc = fb_check_args(outerc, ws, n);
+  if (rc) return rc;
+  if (bn_type == OZK_G1)
+    return fixed_batch_dev<G1Cfg>(outerc, ws, n, d_base, d_scalars, d_out, 48, d_workspace, workspace_bytes,
+                                  (hipStream_t)stream);
+  return fixed_batch_dev<G2Cfg>(outerc, ws, n, d_base, d_scalars, d_out, 96, d_workspace, workspace_bytes,
+                                (hipStream_t)stream);
+}
+
+int ozk_fixed_batch_msm_host(int32_t outerc, int32_t ws, int32_t out_len, int32_t inner_len, int32_t n,
+                             int32_t scalar_size, const uint8_t* base, const uint8_t* scalars, int32_t bn_type,
+                             int32_t task_id, uint8_t* out) {
+  (void)out_len; (void)inner_len; (void)scalar_size;  // table shape is implied by outerc / windowSize
+  if (!base || !scalars || !out) return fail(OZK_E_INVALID, "null pointer argument");
+  int rc = fb_check_args(outerc, ws, n);
+  if (rc) return rc;
+  if ((rc = select_device(task_id))) return rc;
+  const bool g1 = bn_type == OZK_G1;
+  const size_t base_bytes = g1 ? 96 : 192, sc_bytes = (size_t)n * 32, out_bytes = (size_t)n * (g1 ? 192 : 384);
+  const size_t wsb = ozk_fixed_batch_msm_workspace_bytes(outerc, ws, n, bn_type);
+  DevBuf d;
+  OZK_HIP(hipStreamCreateWithFlags(&d.st, hipStreamNonBlocking));
+  const size_t a0 = 256, a1 = a0 + ((sc_bytes + 255) & ~(size_t)255), a2 = a1 + ((out_bytes + 255) & ~(size_t)255);
+  OZK_HIP(hipMalloc((void**)&d.p, a2 + wsb + 256));
+  OZK_HIP(hipMemcpyAsync(d.p, base, base_bytes, hipMemcpyHostToDevice, d.st));
+  OZK_HIP(hipMemcpyAsync(d.p + a0, scalars, sc_bytes, hipMemcpyHostToDevice, d.st));
+  rc = ozk_fixed_batch_msm_dev(outerc, ws, n, d.p, d.p + a0, bn_type, d.p + a1, d.p + a2, wsb, d.st);
+  if (rc) return rc;
+  OZK_HIP(hipMemcpyAsync(out, d.p + a1, out_bytes, hipMemcpyDeviceToHost, d.st));
+  OZK_HIP(hipStreamSynchronize(d.st));
+  return OZK_OK;
+}
+
+int ozk_fixed_double_batch_msm_host(int32_t outerc1, int32_t ws1, int32_t outerc2, int32_t ws2, int32_t out_len1,
+                                    int32_t inner_len1, int32_t out_len2, int32_t inner_len2, int32_t n,
+                                    const uint8_t* base_g1, const uint8_t* base_g2, const uint8_t* scalars,
+                                    int32_t task_id, uint8_t* out) {
+  (void)out_len1; (void)inner_len1; (void)out_len2; (void)inner_len2;
+  if (!base_g1 || !base_g2 || !scalars || !out) return fail(OZK_E_INVALID, "null pointer argument");
+  int rc = fb_check_args(outerc1, ws1, n);
+  if (rc) return rc;
+  if ((rc = fb_check_args(outerc2, ws2, n))) return rc;
+  if ((rc = select_device(task_id))) return rc;
+  // per element G1 (3 x 64 BE) || G2 (6 x 64 BE) = 576 B  (FixedBaseMSM.cu:1479-1482)
+  const size_t sc_bytes = (size_t)n * 32, out_bytes = (size_t)n * 576;
+  const size_t w1 = fb_layout<G1Cfg>(outerc1, ws1, n, nullptr, 0).bytes;
+  const size_t w2 = fb_layout<G2Cfg>(outerc2, ws2, n, nullptr, 0).bytes;
+  const size_t wsb = w1 > w2 ? w1 : w2;
+  DevBuf d;
+  OZK_HIP(hipStreamCreateWithFlags(&d.st, hipStreamNonBlocking));
+  const size_t a0 = 512, a1 = a0 + ((sc_bytes + 255) & ~(size_t)255), a2 = a1 + ((out_bytes + 255) & ~(size_t)255);
+  OZK_HIP(hipMalloc((void**)&d.p, a2 + wsb + 256));
+  OZK_HIP(hipMemcpyAsync(d.p, base_g1, 96, hipMemcpyHostToDevice, d.st));
+  OZK_HIP(hipMemcpyAsync(d.p + 256, base_g2, 192, hipMemcpyHostToDevice, d.st));
+  OZK_HIP(hipMemcpyAsync(d.p + a0, scalars, sc_bytes, hipMemcpyHostToDevice, d.st));
+  rc = fixed_batch_dev<G1Cfg>(outerc1, ws1, n, d.p, d.p + a0, d.p + a1, 144, d.p + a2, wsb, d.st);
+  if (rc) return rc;
+  rc = fixed_batch_dev<G2Cfg>(outerc2, ws2, n, d.p + 256, d.p + a0, d.p + a1 + 192, 144, d.p + a2, wsb, d.st);
+  if (rc) return rc;
+  OZK_HIP(hipMemcpyAsync(out, d.p + a1, out_bytes, hipMemcpyDeviceToHost, d.st));
+  OZK_HIP(hipStreamSynchronize(d.st));
+  return OZK_OK;
+}
+
+int ozk_field_batch_mul_dev(const void* d_in, int32_t n, void* d_out, void* stream) {
+  if (!d_in || !d_out || n <= 0) return fail(OZK_E_INVALID, "bad argument");
+  hipLaunchKernelGGL(k_field_mul, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const u32*)d_in, n,
+                     (u32*)d_out);
+  OZK_HIP(hipGetLastError());
+  return OZK_OK;
+}
+
+int ozk_field_batch_mul_host(const uint8_t* in, int32_t n, int32_t task_id, uint8_t* out) {
+  if (!in || !out) return fail(OZK_E_INVALID, "null pointer argument");
+  if (n <= 0 || n > (1 << 24)) return fail(OZK_E_INVALID, "batch_size %d out of range", n);
+  int rc = select_device(task_id);
+  if (rc) return rc;
+  const size_t in_bytes = (size_t)(n + 1) * 32, out_bytes = (size_t)n * 64;
+  DevBuf d;
+  OZK_HIP(hipStreamCreateWithFlags(&d.st, hipStreamNonBlocking));
+  const size_t a1 = (in_bytes + 255) & ~(size_t)255;
+  OZK_HIP(hipMalloc((void**)&d.p, a1 + out_bytes + 256));
+  OZK_HIP(hipMemcpyAsync(d.p, in, in_bytes, hipMemcpyHostToDevice, d.st));
+  rc = ozk_field_batch_mul_dev(d.p, n, d.p + a1, d.st);
+  if (rc) return rc;
+  OZK_HIP(hipMemcpyAsync(out, d.p + a1, out_bytes, hipMemcpyDeviceToHost, d.st));
+  OZK_HIP(hipStreamSynchronize(d.st));
+  return OZK_OK;
+}
+
+}  // extern "C"

@@ -362,15 +362,6 @@ __device__ void write_normalised(const Jac<CV>& r, u32* out) {
 }
 
 // A_w holds S_w (one element per window after the last wsum level, with 2^g * 0 * R = 0).
-// hipcc scalarises a provably wave-uniform computation onto the SALU, where the 64-bit
-// MAD chains run ~4x slower (measured: 11.6 us per doubling); an opaque zero in a VGPR
-// keeps the serial tail on the vector ALU.
-__device__ __forceinline__ u32 opaque_zero() {
-  u32 z;
-  asm volatile("v_mov_b32 %0, 0" : "=v"(z));
-  return z;
-}
-
 template <class CV>
 __global__ void __launch_bounds__(64) k_finalize(const u32* __restrict__ A_w, int W, int c, u32* __restrict__ out) {
   using IO = CurveIO<CV>;

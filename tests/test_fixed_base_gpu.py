@@ -1,0 +1,76 @@
+"""GPU parity tests of FixedBaseMSM / field batch multiplication through the C ABI."""
+import random
+
+import pytest
+
+from oracle import bn254 as o
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fixed_base_golden():
+    from octopuszk_amd import fixed_base_msm as fb
+    for case in gu.load("fixed_base.json")["cases"]:
+        if case["curve"] in ("G1", "G2"):
+            sc = bytes.fromhex(case["scalars"])
+            n = len(sc) // 32
+            w = case["window"]
+            num_windows = case["outerc"]
+            got = fb.batch_msm_native_helper(case["outerc"], w, num_windows, 1 << w, n, case["scalar_size"],
+                                             bytes.fromhex(case["base"]), sc, 1 if case["curve"] == "G1" else 2, 0)
+            assert got == bytes.fromhex(case["expected_out"]), (case["curve"], w)
+        else:
+            got = fb.field_batch_msm_native_helper(bytes.fromhex(case["field_mul_in"]), case["n"], 0)
+            assert got == bytes.fromhex(case["expected_out"])
+
+
+@pytest.mark.parametrize("n,window", [(1, 1), (5, 3), (300, 8), (1000, 11)])
+def test_fixed_base_g1_vs_oracle(n, window):
+    from octopuszk_amd import fixed_base_msm as fb
+    rng = random.Random(n + window)
+    base = o.G1.mul(o.G1.one, rng.randrange(1, o.R))          # Jacobian base, Z != 1
+    scalars = [rng.randrange(o.R) for _ in range(n)]
+    scalars[0] = 0
+    got = fb.batch_msm(254, window, base, scalars, is_g1=True)
+    for s, P in zip(scalars, got):
+        assert P == o.G1.to_affine(o.fixed_base_mul(o.G1, base, 254, window, s))
+
+
+def test_fixed_base_truncates_to_outerc_windows():
+    # only the first outerc windows of the scalar are used (FixedBaseMSM.java:146-164)
+    from octopuszk_amd import fixed_base_msm as fb
+    base = o.G1.to_affine(o.G1.mul(o.G1.one, 5))
+    scalars = [(1 << 200) + 77, 12345]
+    got = fb.batch_msm(64, 8, base, scalars, is_g1=True)     # scalarSize 64 -> 8 windows of 8 bits
+    assert got[0] == o.G1.to_affine(o.G1.mul(base, 77))
+    assert got[1] == o.G1.to_affine(o.G1.mul(base, 12345))
+
+
+def test_fixed_base_g2_and_double():
+    from octopuszk_amd import fixed_base_msm as fb
+    from octopuszk_amd.variable_base_msm import marshal_scalars
+    rng = random.Random(77)
+    b1 = o.G1.to_affine(o.G1.mul(o.G1.one, 31337))
+    b2 = o.G2.mul(o.G2.one, 424242)
+    scalars = [0, 1, o.R - 1] + [rng.randrange(o.R) for _ in range(20)]
+    got2 = fb.batch_msm(254, 5, b2, scalars, is_g1=False)
+    for s, P in zip(scalars, got2):
+        assert P == o.G2.to_affine(o.fixed_base_mul(o.G2, b2, 254, 5, s))
+    w1, w2 = 6, 4
+    oc1, oc2 = (254 + w1 - 1) // w1, (254 + w2 - 1) // w2
+    raw = fb.double_batch_msm_native_helper(oc1, w1, oc2, w2, oc1, 1 << w1, oc2, 1 << w2, len(scalars),
+                                            o.g1_to_wire(b1), o.g2_to_wire(b2), marshal_scalars(scalars), 0)
+    for i, s in enumerate(scalars):
+        rec = raw[576 * i: 576 * (i + 1)]
+        assert rec[:192] == o.g1_out_be(o.G1.to_affine(o.G1.mul(b1, s)))
+        assert rec[192:] == o.g2_out_be(o.G2.to_affine(o.G2.mul(b2, s)))
+
+
+def test_field_batch_mul():
+    from octopuszk_amd import fixed_base_msm as fb
+    rng = random.Random(3)
+    xs = [0, 1, o.R - 1] + [rng.randrange(o.R) for _ in range(500)]
+    m = rng.randrange(o.R)
+    got = fb.field_batch_msm_native_helper(b"".join(o.to_le32(x) for x in xs + [m]), len(xs), 0)
+    assert got == b"".join(int(x * m % o.R).to_bytes(64, "big") for x in xs)
