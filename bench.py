@@ -76,16 +76,14 @@ def main():
     sc_host = rand_scalars(n, 1 + rank)
     scalars = torch.from_numpy(sc_host).cuda()
     ws = dev.VarMsmWorkspace(n, 1)
-    gathered = torch.zeros(world * 192, dtype=torch.uint8, device="cuda") if world > 1 else None
     wb, wn = ctypes.c_int32(), ctypes.c_int32()
     ozk.check(L.ozk_var_msm_plan(n, ctypes.byref(wb), ctypes.byref(wn)))
 
+    from octopuszk_amd import distributed as ozk_dist
+
     def step():
-        out = ws.run(bases, scalars)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, out)
-            return dev.points_sum(gathered, world, 1)
-        return out
+        # local HIP MSM; for N > 1: RCCL all-gather of the 192-B partials + HIP point sum
+        return ozk_dist.gpu_var_msm(ws, bases, scalars)
 
     def barrier():
         if world > 1:

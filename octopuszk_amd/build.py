@@ -19,9 +19,9 @@ HIP_SOURCES = ["msm_var.hip", "msm_fixed.hip", "fft.hip"]
 HEADERS = ["consts_gen.h", "fp29.cuh", "fq2.cuh", "ec.cuh", "curve.cuh", "msm_var.cuh", "ozk_common.h",
            os.path.join("..", "..", "include", "ozk.h")]
 JNI_LIBS = {
-    "libAlgebraMSMVariableBaseMSM.so": "jni_var_msm.cpp",
-    "libAlgebraMSMFixedBaseMSM.so": "jni_fixed_msm.cpp",
-    "libAlgebraFFTAuxiliary.so": "jni_fft.cpp",
+    "libAlgebraMSMVariableBaseMSM.so": "jni_var_msm.c",
+    "libAlgebraMSMFixedBaseMSM.so": "jni_fixed_msm.c",
+    "libAlgebraFFTAuxiliary.so": "jni_fft.c",
 }
 
 
@@ -57,8 +57,9 @@ def build(force=False, verbose=True):
         if not os.path.exists(s):
             continue
         out = os.path.join(HERE, lib)
-        if force or _newer(out, [s, os.path.join(ROOT, "include", "ozk_jni.h"), os.path.join(ROOT, "include", "ozk.h"), LIB]):
-            cmd = ["g++", "-std=c++17", "-O2", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"),
+        if force or _newer(out, [s, os.path.join(CSRC, "jni_common.h"), os.path.join(ROOT, "include", "ozk_jni.h"),
+                                 os.path.join(ROOT, "include", "ozk.h")]):
+            cmd = ["gcc", "-std=c11", "-O2", "-Wall", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"),
                    "-o", out, s, "-L", HERE, "-lozk_hip", "-Wl,-rpath,$ORIGIN"]
             if verbose:
                 print(" ".join(cmd), flush=True)

@@ -1,0 +1,48 @@
+/* libAlgebraFFTAuxiliary.so — JNI native of algebra.fft.FFTAuxiliary
+ * (replaces algebra_fft_FFTAuxiliary.cu:219-260).  The List<byte[]> is walked with
+ * List.size()/get(i) like the reference does (FFT.cu:224-235), each element copied with
+ * GetByteArrayRegion into a flat n x 32 B buffer and its local reference deleted (the
+ * reference leaks one local ref and one pinned array per element). */
+#include "jni_common.h"
+
+JNIEXPORT jbyteArray JNICALL Java_algebra_fft_FFTAuxiliary_serialRadix2FFTNativeHelper(
+    JNIEnv* env, jclass cls, jobject inputs, jbyteArray omega, jint taskID) {
+  (void)cls;
+  if (!inputs || !omega) return ozk_throw(env, "null argument");
+  jclass list = (*env)->FindClass(env, "java/util/List");
+  if (!list) return NULL;
+  jmethodID m_size = (*env)->GetMethodID(env, list, "size", "()I");
+  jmethodID m_get = (*env)->GetMethodID(env, list, "get", "(I)Ljava/lang/Object;");
+  if (!m_size || !m_get) return NULL;
+  const jint n = (*env)->CallIntMethod(env, inputs, m_size);
+  if ((*env)->ExceptionCheck(env)) return NULL;
+  if (n <= 0 || (n & (n - 1))) return ozk_throw(env, "FFT input size must be a power of two");
+  uint8_t* flat = (uint8_t*)calloc((size_t)n, 32);
+  uint8_t* out = (uint8_t*)malloc((size_t)n * 64);
+  if (!flat || !out) { free(flat); free(out); return ozk_throw(env, "out of host memory"); }
+  jbyteArray result = NULL;
+  int ok = 1;
+  for (jint i = 0; i < n && ok; i++) {
+    jbyteArray el = (jbyteArray)(*env)->CallObjectMethod(env, inputs, m_get, i);
+    if ((*env)->ExceptionCheck(env) || !el) { ok = 0; break; }
+    const jsize len = (*env)->GetArrayLength(env, el);
+    if (len > 32) { ozk_throw(env, "FFT element longer than 32 bytes"); ok = 0; }
+    else (*env)->GetByteArrayRegion(env, el, 0, len, (jbyte*)(flat + (size_t)i * 32));
+    (*env)->DeleteLocalRef(env, el);
+  }
+  uint8_t om[32];
+  memset(om, 0, sizeof(om));
+  if (ok) {
+    const jsize olen = (*env)->GetArrayLength(env, omega);
+    if (olen > 32) { ozk_throw(env, "omega longer than 32 bytes"); ok = 0; }
+    else (*env)->GetByteArrayRegion(env, omega, 0, olen, (jbyte*)om);
+  }
+  if (ok) {
+    const int rc = ozk_fft_host(flat, n, om, taskID, out);
+    if (rc) ozk_throw_last(env, "serialRadix2FFTNativeHelper", rc);
+    else result = ozk_result(env, out, 64LL * n);
+  }
+  free(flat);
+  free(out);
+  return result;
+}

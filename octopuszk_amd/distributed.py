@@ -1,0 +1,46 @@
+"""Multi-GPU variable-base MSM: one process per GPU (torch.distributed, backend "nccl" =
+RCCL over xGMI), index-range sharding, one tiny exchange.
+
+Mirrors VariableBaseMSM.distributedMSM (VariableBaseMSM.java:775-786): Spark's
+`mapPartitions(serialMSMPartition) -> reduce(GroupT::add)` becomes: every rank runs the
+single-GPU pipeline on its contiguous slice of (scalar, base) pairs, the ranks all-gather
+their 192-byte (G1) / 384-byte (G2) affine partials, and every rank adds the world_size
+partials with the HIP point-sum kernel.  RCCL has no elliptic-curve reduction operator, so
+the "all-reduce" is all-gather + local sum; the message is < 4 KiB, i.e. latency-bound, and
+there is no other data-path collective.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n: int, rank: int, world: int):
+    """Contiguous slice [lo, hi) of n pairs owned by `rank` (sizes differ by at most 1)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def all_gather_partials(partial: torch.Tensor, group=None) -> torch.Tensor:
+    """partial: uint8 [192|384] on this rank's device -> uint8 [world * len] (rank order)."""
+    world = dist.get_world_size(group)
+    out = torch.empty(world * partial.numel(), dtype=torch.uint8, device=partial.device)
+    dist.all_gather_into_tensor(out, partial.contiguous(), group=group)
+    return out
+
+
+def distributed_var_msm(local_partial_fn, sum_fn, type_: int = 1, group=None) -> torch.Tensor:
+    """local_partial_fn() -> this rank's partial (wire-out bytes tensor);
+    sum_fn(gathered, world, type_) -> the normalised sum.  The defaults used on GPUs are
+    device.VarMsmWorkspace.run and device.points_sum; tests inject CPU stand-ins over gloo."""
+    partial = local_partial_fn()
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return partial
+    gathered = all_gather_partials(partial, group)
+    return sum_fn(gathered, dist.get_world_size(group), type_)
+
+
+def gpu_var_msm(ws, d_bases, d_scalars, group=None) -> torch.Tensor:
+    """The production composition on one rank: HIP MSM on the local slice + RCCL all-gather +
+    HIP point sum.  `ws` is a device.VarMsmWorkspace for the local slice size."""
+    from . import device as dev
+    return distributed_var_msm(lambda: ws.run(d_bases, d_scalars), dev.points_sum, ws.type, group)

@@ -1,0 +1,62 @@
+"""The six JNI natives driven through a mock JNIEnv on the GPU: same bytes as the oracle."""
+import random
+
+import pytest
+
+from oracle import bn254 as o
+import jni_util as ju
+
+pytestmark = pytest.mark.gpu
+
+
+def _pts(C, n, rng):
+    return [C.to_affine(C.mul(C.one, rng.randrange(1, 1 << 64))) for _ in range(n)]
+
+
+def test_jni_var_msm_g1_g2_double():
+    rng = random.Random(42)
+    n = 33
+    b1, b2 = _pts(o.G1, n, rng), _pts(o.G2, n, rng)
+    sc = [rng.randrange(o.R) for _ in range(n)]
+    w1 = b"".join(o.g1_to_wire(P) for P in b1)
+    w2 = b"".join(o.g2_to_wire(P) for P in b2)
+    ws = b"".join(o.to_le32(s) for s in sc)
+    e1 = o.g1_out_le(o.G1.to_affine(o.naive_msm(o.G1, sc, b1)))
+    e2 = o.g2_out_le(o.G2.to_affine(o.naive_msm(o.G2, sc, b2)))
+    assert ju.var_msm(w1, ws, n, 1) == e1
+    assert ju.var_msm(w2, ws, n, 2) == e2
+    assert ju.var_double_msm(w1, w2, ws, n) == e1 + e2
+    assert ju.var_msm(w1, ws, n, 1, task=7) == e1   # taskID % num_gpus
+
+
+def test_jni_fixed_base_and_field():
+    rng = random.Random(43)
+    sc = [0, 1, o.R - 1] + [rng.randrange(o.R) for _ in range(10)]
+    ws = b"".join(o.to_le32(s) for s in sc)
+    B1 = o.G1.mul(o.G1.one, 777)
+    B2 = o.G2.to_affine(o.G2.mul(o.G2.one, 888))
+    w = 7
+    oc = (254 + w - 1) // w
+    got = ju.fixed_batch(oc, w, len(sc), 254, o.g1_to_wire(B1), ws, 1)
+    assert got == b"".join(o.g1_out_be(o.G1.to_affine(o.G1.mul(B1, s))) for s in sc)
+    got = ju.fixed_batch(oc, w, len(sc), 254, o.g2_to_wire(B2), ws, 2)
+    assert got == b"".join(o.g2_out_be(o.G2.to_affine(o.G2.mul(B2, s))) for s in sc)
+    got = ju.fixed_double_batch(oc, w, oc, w, len(sc), o.g1_to_wire(B1), o.g2_to_wire(B2), ws)
+    assert got == b"".join(o.g1_out_be(o.G1.to_affine(o.G1.mul(B1, s))) + o.g2_out_be(o.G2.to_affine(o.G2.mul(B2, s)))
+                           for s in sc)
+    m = rng.randrange(o.R)
+    got = ju.field_mul(ws + o.to_le32(m), len(sc))
+    assert got == b"".join(int(s * m % o.R).to_bytes(64, "big") for s in sc)
+
+
+def test_jni_fft_list_walk():
+    rng = random.Random(44)
+    n = 256
+    a = [rng.randrange(o.R) for _ in range(n)]
+    a[3], a[4] = 0, 1                       # short encodings (4 bytes) in the List<byte[]>
+    w = o.fr_root_of_unity(n)
+    got, refs = ju.fft([o.to_fft_bytes(x) for x in a], o.to_fft_bytes(w))
+    b = list(a)
+    o.serial_radix2_fft(b, w)
+    assert got == b"".join(int(x).to_bytes(64, "little") for x in b)
+    assert refs == n                         # every element's local reference was deleted
