@@ -49,6 +49,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--logn", type=int, default=LOGN)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="MSMs in flight: the latency-bound tail of step k runs on a side stream while the "
+                         "head of step k+1 runs (1 = strictly serial steps)")
     args = ap.parse_args()
 
     import torch
@@ -75,33 +78,50 @@ def main():
     bases = dev.gen_g1_bases(n, seed=2 + (rank << 32))
     sc_host = rand_scalars(n, 1 + rank)
     scalars = torch.from_numpy(sc_host).cuda()
-    ws = dev.VarMsmWorkspace(n, 1)
+    pipe = dev.VarMsmPipeline(n, 1, depth=max(1, args.in_flight))
     wb, wn = ctypes.c_int32(), ctypes.c_int32()
     ozk.check(L.ozk_var_msm_plan(n, ctypes.byref(wb), ctypes.byref(wn)))
 
     from octopuszk_amd import distributed as ozk_dist
 
-    def step():
-        # local HIP MSM; for N > 1: RCCL all-gather of the 192-B partials + HIP point sum
-        return ozk_dist.gpu_var_msm(ws, bases, scalars)
+    def finish(ticket):
+        # the step's result; for N > 1: RCCL all-gather of the 192-B partials + HIP point sum
+        return ozk_dist.distributed_var_msm(lambda: pipe.result(ticket), dev.points_sum, 1)
+
+    def run_steps(k):
+        """k complete MSMs; step i's tail overlaps step i+1's head (args.in_flight > 1)."""
+        res, prev = None, None
+        for _ in range(k):
+            t = pipe.submit(bases, scalars)
+            if prev is not None:
+                res = finish(prev)
+            prev = t
+        return finish(prev)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        res = step()
+    res = run_steps(max(1, args.warmup))
     barrier()
     ozk.check(L.ozk_prof_enable(1))
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
+    res = run_steps(args.steps)
     barrier()
     t1 = time.perf_counter()
     avg_ms, launches = ctypes.c_double(), ctypes.c_int()
     ozk.check(L.ozk_prof_dominant_kernel_ms(ctypes.byref(avg_ms), ctypes.byref(launches)))
     ozk.check(L.ozk_prof_enable(0))
+    # latency of ONE MSM with nothing else in flight (not part of `value`)
+    lat = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        l0 = time.perf_counter()
+        finish(pipe.submit(bases, scalars))
+        torch.cuda.synchronize()
+        lat.append(time.perf_counter() - l0)
+    single_ms = sorted(lat)[len(lat) // 2] * 1e3
 
     elapsed = t1 - t0
     if world > 1:
@@ -148,6 +168,7 @@ def main():
                 "config": {"workload": "VariableBaseMSM BN254 G1 2^%d random scalars/bases per GPU, bit-exact vs "
                                        "the serial CPU path (BASELINE.json configs[1])" % args.logn,
                            "n_per_gpu": n, "window_bits": wb.value, "windows": wn.value,
+                           "msms_in_flight": max(1, args.in_flight), "single_msm_latency_ms": round(single_ms, 3),
                            "parallelism": "index-range shard x%d, RCCL all-gather of 192-B partials + HIP point sum" % world},
                 "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)

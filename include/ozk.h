@@ -67,6 +67,21 @@ int ozk_var_double_msm_host(const uint8_t* bases_g1, const uint8_t* bases_g2,
 size_t ozk_var_msm_workspace_bytes(int32_t n, int32_t type);
 int ozk_var_msm_dev(const void* d_bases, const void* d_scalars, int32_t n, int32_t type,
                     void* d_out, void* d_workspace, size_t workspace_bytes, void* stream);
+/* The same MSM in two phases, for callers that keep several MSMs in flight (a Groth16 prove
+ * has six independent ones): the HEAD is the throughput-bound part (sort, bucket accumulation,
+ * first window-sum level) and leaves its result in `d_tail` (ozk_var_msm_tail_bytes bytes);
+ * the TAIL is the latency-bound remainder (upper window-sum levels, Horner over the windows,
+ * normalisation; a few lanes busy for ~2 ms) and reads nothing but `d_tail`.  Running the tail
+ * on a second stream lets the next MSM's head (which may reuse the same workspace) overlap
+ * it.  ozk_var_msm_dev == head + tail on one stream. */
+size_t ozk_var_msm_head_workspace_bytes(int32_t n, int32_t type);
+size_t ozk_var_msm_tail_bytes(int32_t n, int32_t type);
+int ozk_var_msm_head_dev(const void* d_bases, const void* d_scalars, int32_t n, int32_t type,
+                         void* d_workspace, size_t workspace_bytes, void* d_tail, size_t tail_bytes,
+                         void* stream);
+int ozk_var_msm_tail_dev(int32_t n, int32_t type, void* d_tail, size_t tail_bytes, void* d_out,
+                         void* stream);
+
 /* sum of k affine-normalised partial results in wire-out format (k x 192 B / 384 B), as
  * produced by ozk_var_msm_dev on k ranks -> one normalised point.  The multi-GPU
  * reduce(GroupT::add) of VariableBaseMSM.java:777-783 after the RCCL all-gather. */

@@ -46,8 +46,26 @@ def build(force=False, verbose=True):
         defs = []
         if os.path.exists(os.path.join(CSRC, "fq2.cuh")):
             defs.append("-DOZK_WITH_G2")
-        cmd = [hipcc(), "-std=c++17", "-O3", "--offload-arch=gfx950", "-shared", "-fPIC",
-               "-Wno-unused-result", "-Wno-pass-failed"] + defs + ["-o", LIB] + srcs
+        # one object per translation unit, compiled in parallel, then one device link
+        objdir = os.path.join(HERE, "_obj")
+        os.makedirs(objdir, exist_ok=True)
+        common = [hipcc(), "-std=c++17", "-O3", "--offload-arch=gfx950", "-fPIC", "-fgpu-rdc" if False else "-fno-gpu-rdc",
+                  "-Wno-unused-result", "-Wno-pass-failed"] + defs
+        procs, objs = [], []
+        for src in srcs:
+            obj = os.path.join(objdir, os.path.basename(src) + ".o")
+            objs.append(obj)
+            if force or _newer(obj, [src] + [os.path.join(CSRC, h) for h in HEADERS]):
+                cmd = common + ["-c", "-o", obj, src]
+                if verbose:
+                    print(" ".join(cmd), flush=True)
+                procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        for cmd, pr in procs:
+            out, _ = pr.communicate()
+            if pr.returncode != 0:
+                sys.stderr.write(out.decode(errors="replace"))
+                raise subprocess.CalledProcessError(pr.returncode, cmd)
+        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

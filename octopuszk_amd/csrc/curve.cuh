@@ -118,6 +118,13 @@ __device__ __forceinline__ u32 opaque_zero() {
   asm volatile("v_mov_b32 %0, 0" : "=v"(z));
   return z;
 }
+template <class P, int B>
+__device__ __forceinline__ Fe<P, B> shfl_down_el(const Fe<P, B>& v, int o) {
+  Fe<P, B> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = __shfl_down(v.l[i], o);
+  return r;
+}
 #endif
 
 }  // namespace ozk

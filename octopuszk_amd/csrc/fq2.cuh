@@ -172,6 +172,16 @@ struct ElemTraits<Fe2<B>> {
   static OZK_HD bool wire_is_one(const u32* p) { return E1::wire_is_one(p) && E1::wire_is_zero(p + 8); }
 };
 
+#if defined(__HIPCC__)
+template <int B>
+__device__ __forceinline__ Fe2<B> shfl_down_el(const Fe2<B>& v, int o) {
+  Fe2<B> r;
+  r.c0 = shfl_down_el(v.c0, o);
+  r.c1 = shfl_down_el(v.c1, o);
+  return r;
+}
+#endif
+
 // G2 over Fq2.  Loop-carried bounds: mul / sqr return < 2p, so the madd outputs are
 // X3 = sqr - (J + 2V) < 2p + 7p, Y3 < 2p + 5p, Z3 < 2p + 5p.
 struct G2Cfg {

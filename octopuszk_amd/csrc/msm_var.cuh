@@ -243,10 +243,20 @@ k_segreduce(const u32* __restrict__ bid_in, const u32* __restrict__ idx_in,
   using IO = CurveIO<CV>;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_lanes) return;
+  // levels >= 2: d_count is the number of partial slots still alive after the pair merge;
+  // 0 means every bucket is already complete and the level has nothing to do
+  if (!FIRST && *d_count == 0) return;
   const long long n_in = FIRST ? (long long)(*d_count) : (long long)n_in_static;
   const long long s = (long long)t * L;
   u32 head_bid = BID_NONE, tail_bid = BID_NONE;
-  if (s < n_in) {
+  bool live = s < n_in;
+  if (!FIRST && live) {  // chunk of empty slots: nothing to reduce (independent loads, pipelined)
+    const long long e0 = (s + L < n_in) ? (s + L) : n_in;
+    bool any = false;
+    for (long long p = s; p < e0; p++) any = any || (bid_in[p] != BID_NONE);
+    live = any;
+  }
+  if (live) {
     const long long e = (s + L < n_in) ? (s + L) : n_in;
     const u32 first_bid = bid_in[s];
     const bool cb = (s > 0) && (bid_in[s - 1] == first_bid) && (first_bid != BID_NONE);
@@ -303,6 +313,51 @@ k_segreduce(const u32* __restrict__ bid_in, const u32* __restrict__ idx_in,
   bid_out[2 * (size_t)t + 1] = tail_bid;
 }
 
+// Run merge between level 1 and the generic levels.  After level 1 a bucket cut by lane
+// boundaries is a run of adjacent slots with the same id (two for almost every bucket; a few
+// more for the top window, whose digits have fewer significant bits).  Every run of at most
+// RUN_MAX slots is summed by the lane that owns its first slot and written to its bucket; all
+// its slots die.  Longer runs (skewed digit distributions) are left to the generic levels and
+// counted in *remaining.  Each lane decides from bid_in alone, so there are no races.
+constexpr int RUN_MAX = 16;
+template <class CV>
+__global__ void __launch_bounds__(256)
+k_runmerge(const u32* __restrict__ bid_in, const u32* __restrict__ pts, int n_slots,
+           u32* __restrict__ buckets, u32* __restrict__ bid_out, u32* __restrict__ remaining) {
+  using IO = CurveIO<CV>;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  u32 alive = 0;
+#pragma unroll 1
+  for (int k = 0; k < 2; k++) {
+    // lane t owns slots 2t+1 and 2t+2; lane 0 also owns slot 0 (always empty: no run starts there)
+    const int x = 2 * t + 1 + k;
+    if (x >= n_slots) break;
+    const u32 bx = bid_in[x];
+    u32 out = BID_NONE;
+    if (bx != BID_NONE) {
+      int s = x, e = x;
+      while (s > 0 && x - s < RUN_MAX && bid_in[s - 1] == bx) s--;
+      while (e + 1 < n_slots && e - x < RUN_MAX && bid_in[e + 1] == bx) e++;
+      const bool is_short = (x - s < RUN_MAX) && (e - x < RUN_MAX) && (e - s + 1 <= RUN_MAX);
+      if (!is_short) {
+        out = bx;
+      } else if (s == x) {  // owner of the run: sum it
+        Jac<CV> acc = IO::load_jac(pts + (size_t)s * IO::JAC_WORDS);
+        for (int q = s + 1; q <= e; q++) acc = jac_add(acc, IO::load_jac(pts + (size_t)q * IO::JAC_WORDS));
+        IO::store_jac(acc, buckets + (size_t)bx * IO::JAC_WORDS);
+      }
+    }
+    bid_out[x] = out;
+    alive += (out != BID_NONE);
+  }
+  if (t == 0 && n_slots > 0) {
+    bid_out[0] = bid_in[0];
+    alive += (bid_in[0] != BID_NONE);
+  }
+  for (int o = 32; o > 0; o >>= 1) alive += __shfl_xor(alive, o);
+  if ((threadIdx.x & 63) == 0 && alive) atomicAdd(remaining, alive);
+}
+
 // ------------------------------------------------------------------ window sums
 // Per window the elements e = 0..m-1 carry (A_e, R_e) with
 //     S_w = sum_e A_e + 2^g * sum_e e * R_e.
@@ -338,6 +393,64 @@ k_wsum(const u32* __restrict__ A_in, const u32* __restrict__ R_in, const u32* __
   if constexpr (!FIRSTLEVEL) ws = jac_add(ws, asum);
   IO::store_jac(ws, A_out + ((size_t)w * m_out + j) * IO::JAC_WORDS);
   IO::store_jac(run, R_out + ((size_t)w * m_out + j) * IO::JAC_WORDS);
+}
+
+// Wave-cooperative window-sum level: one wave per 64 consecutive elements of one window.
+//   T_l  = sum_{l' >= l} R_l'          suffix scan by shuffles           (log2 steps)
+//   V_l  = A_l + 2^g * (l >= 1 ? T_l : 0)                                (g doublings, in parallel)
+//   A'   = sum_l V_l                   tree reduction by shuffles        (log2 steps)
+//   R'   = T_0
+// since sum_{l>=1} T_l = sum_l l * R_l.  13 dependent additions per 64x reduction instead of
+// the 24 per 8x of the serial form: the upper levels are latency-bound, not throughput-bound.
+template <class CV>
+__device__ __forceinline__ Jac<CV> shfl_down_jac(const Jac<CV>& p, int o) {
+  Jac<CV> r;
+  r.X = shfl_down_el(p.X, o);
+  r.Y = shfl_down_el(p.Y, o);
+  r.Z = shfl_down_el(p.Z, o);
+  return r;
+}
+
+template <class CV>
+__global__ void __launch_bounds__(64)
+k_wsum_wave(const u32* __restrict__ A_in, const u32* __restrict__ R_in, int m_in, int g,
+            u32* __restrict__ A_out, u32* __restrict__ R_out, int m_out, int W) {
+  using IO = CurveIO<CV>;
+  const int wave = blockIdx.x;  // one 64-lane block per (window, group of 64 elements)
+  if (wave >= m_out * W) return;
+  const int w = wave / m_out, j = wave - w * m_out;
+  const int l = threadIdx.x & 63;
+  const int e = j * 64 + l;
+  int valid = m_in - j * 64;
+  if (valid > 64) valid = 64;
+  Jac<CV> A = jac_infinity<CV>(), T = jac_infinity<CV>();
+  if (e < m_in) {
+    A = IO::load_jac(A_in + ((size_t)w * m_in + e) * IO::JAC_WORDS);
+    T = IO::load_jac(R_in + ((size_t)w * m_in + e) * IO::JAC_WORDS);
+  }
+  // suffix scan of R
+  for (int o = 1; o < valid; o <<= 1) {
+    const Jac<CV> t = shfl_down_jac(T, o);
+    const Jac<CV> s = jac_add(T, t);
+    if (l + o < 64) T = s;
+  }
+  // V = A + 2^g * (l >= 1 ? T : inf)
+  Jac<CV> U = T;
+  for (int k = 0; k < g; k++) U = jac_dbl(U);
+  const Jac<CV> AV = jac_add(A, U);
+  Jac<CV> V = (l >= 1) ? AV : A;
+  // tree reduction of V
+  int top = 1;
+  while (top < valid) top <<= 1;
+  for (int o = top >> 1; o > 0; o >>= 1) {
+    const Jac<CV> v = shfl_down_jac(V, o);
+    const Jac<CV> s = jac_add(V, v);
+    if (l < o) V = s;
+  }
+  if (l == 0) {
+    IO::store_jac(V, A_out + ((size_t)w * m_out + j) * IO::JAC_WORDS);
+    IO::store_jac(T, R_out + ((size_t)w * m_out + j) * IO::JAC_WORDS);
+  }
 }
 
 // ------------------------------------------------------------------ finalize

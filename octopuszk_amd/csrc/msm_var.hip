@@ -5,11 +5,12 @@
 
 #include <vector>
 
+#ifndef OZK_WITH_G2
+#define OZK_WITH_G2 1
+#endif
 #include "msm_var.cuh"
 #include "ozk_common.h"
-#if defined(OZK_WITH_G2)
 #include "fq2.cuh"
-#endif
 
 namespace ozk {
 
@@ -36,7 +37,7 @@ static MsmPlan make_plan(int n) {
   if (c > 16) c = 16;
   p.c = c;
   p.W = (256 + c - 1) / c;
-  p.L1 = env_int("OZK_MSM_L1", 16);
+  p.L1 = env_int("OZK_MSM_L1", 32);
   p.LK = env_int("OZK_MSM_LK", 16);
   if (p.L1 < 2) p.L1 = 2;
   if (p.LK < 4) p.LK = 4;
@@ -49,11 +50,11 @@ static MsmPlan make_plan(int n) {
 struct MsmLayout {
   // all device pointers into the workspace
   u32* aff;
-  u32 *hist, *offs, *blocksum, *total;
+  u32 *hist, *offs, *blocksum, *total;  // total[0] = sorted entries, total[1] = live partial slots
   uint16_t* digits;
   u32 *ranks, *sidx, *sbid;
   u32* buckets;
-  u32 *slot_bid[2], *slot_pts[2];
+  u32 *slot_bid[2], *slot_pts[2], *slot_bid2;
   u32 *wA[2], *wR[2];
   size_t bytes;
   size_t cap;   // n * W sorted entries at most
@@ -85,30 +86,49 @@ static MsmLayout make_layout(const MsmPlan& p, void* ws, size_t ws_bytes) {
   L.slots1 = 2 * T2;
   L.slot_bid[0] = b.take<u32>(L.slots0);
   L.slot_pts[0] = b.take<u32>(L.slots0 * IO::JAC_WORDS);
+  L.slot_bid2 = b.take<u32>(L.slots0);
   L.slot_bid[1] = b.take<u32>(L.slots1);
   L.slot_pts[1] = b.take<u32>(L.slots1 * IO::JAC_WORDS);
   L.m1 = (((size_t)1 << p.c) + p.S - 1) / p.S;
-  for (int k = 0; k < 2; k++) {
-    L.wA[k] = b.take<u32>((size_t)p.W * L.m1 * IO::JAC_WORDS);
-    L.wR[k] = b.take<u32>((size_t)p.W * L.m1 * IO::JAC_WORDS);
-  }
   b.take<u32>(64);
   L.bytes = b.off;
   return L;
 }
 
+// The "tail" buffers (window-sum elements): the only state the latency-bound tail phase reads.
+// They live outside the main workspace so that a caller can keep several MSMs in flight: the
+// head phase of the next MSM may reuse the whole main workspace while this MSM's tail still
+// runs on another stream.
 template <class CV>
-static int var_msm_dev(const void* d_bases, const void* d_scalars, int n, void* d_out, void* ws,
-                       size_t ws_bytes, hipStream_t st) {
+static size_t tail_layout(const MsmPlan& p, MsmLayout& L, void* tail, size_t tail_bytes) {
+  using IO = CurveIO<CV>;
+  Bump b(tail, tail_bytes);
+  for (int k = 0; k < 2; k++) {
+    L.wA[k] = b.take<u32>((size_t)p.W * L.m1 * IO::JAC_WORDS);
+    L.wR[k] = b.take<u32>((size_t)p.W * L.m1 * IO::JAC_WORDS);
+  }
+  b.take<u32>(64);
+  return b.off;
+}
+
+// Head phase: everything that is throughput-bound (conversion, sort, bucket accumulation, run
+// merge, the first window-sum level).  Leaves W * 2^c / S window-sum elements in the tail buffers.
+template <class CV>
+static int var_msm_head(const void* d_bases, const void* d_scalars, int n, void* ws, size_t ws_bytes, void* tail,
+                        size_t tail_bytes, hipStream_t st) {
+  using CT = CV;  // (an out-of-line-multiplication variant for the tails measured 40 % slower)
   const MsmPlan p = make_plan(n);
-  const MsmLayout L = make_layout<CV>(p, ws, ws_bytes);
+  MsmLayout L = make_layout<CV>(p, ws, ws_bytes);
   if (L.bytes > ws_bytes)
     return fail(OZK_E_INVALID, "workspace too small: need %zu bytes, got %zu", L.bytes, ws_bytes);
+  const size_t tneed = tail_layout<CV>(p, L, tail, tail_bytes);
+  if (tneed > tail_bytes) return fail(OZK_E_INVALID, "tail buffer too small: need %zu bytes, got %zu", tneed, tail_bytes);
   const int TB = 256;
   const u32* bases = (const u32*)d_bases;
   const u32* scalars = (const u32*)d_scalars;
 
   OZK_HIP(hipMemsetAsync(L.hist, 0, L.NB * sizeof(u32), st));
+  OZK_HIP(hipMemsetAsync(L.total, 0, 4 * sizeof(u32), st));
   hipLaunchKernelGGL((k_convert_bases<CV>), dim3((n + TB - 1) / TB), dim3(TB), 0, st, bases, L.aff, n);
   hipLaunchKernelGGL(k_digits, dim3((n + TB - 1) / TB), dim3(TB), 0, st, scalars, n, p.c, p.W, L.hist,
                      L.digits, L.ranks);
@@ -128,45 +148,87 @@ static int var_msm_dev(const void* d_bases, const void* d_scalars, int n, void* 
                      L.sbid, L.sidx, L.aff, L.total, 0, p.L1, L.buckets, L.slot_bid[0], L.slot_pts[0],
                      (int)lanes);
   if (prof) hipEventRecord(g_prof.e1[g_prof.count++], st);
-  // levels >= 2 over the partial slots, ping-pong, until a single lane has seen everything
+  // run merge: completes every bucket cut into at most RUN_MAX pieces; counts the surviving slots
   size_t n_in = 2 * lanes;
+  hipLaunchKernelGGL((k_runmerge<CT>), dim3((unsigned)((lanes + TB - 1) / TB)), dim3(TB), 0, st, L.slot_bid[0],
+                     L.slot_pts[0], (int)n_in, L.buckets, L.slot_bid2, L.total + 1);
+  // levels >= 2 over the surviving partial slots, ping-pong, until a single lane has seen everything
+  // (they return at once when nothing survived)
   int cur = 0;
+  bool first_generic = true;
   while (true) {
     lanes = (n_in + p.LK - 1) / p.LK;
-    hipLaunchKernelGGL((k_segreduce<CV, false>), dim3((unsigned)((lanes + TB - 1) / TB)), dim3(TB), 0, st,
-                       L.slot_bid[cur], (const u32*)nullptr, L.slot_pts[cur], (const u32*)nullptr,
-                       (int)n_in, p.LK, L.buckets, L.slot_bid[cur ^ 1], L.slot_pts[cur ^ 1], (int)lanes);
+    hipLaunchKernelGGL((k_segreduce<CT, false>), dim3((unsigned)((lanes + TB - 1) / TB)), dim3(TB), 0, st,
+                       first_generic ? L.slot_bid2 : L.slot_bid[cur], (const u32*)nullptr, L.slot_pts[cur],
+                       L.total + 1, (int)n_in, p.LK, L.buckets, L.slot_bid[cur ^ 1], L.slot_pts[cur ^ 1], (int)lanes);
+    first_generic = false;
     if (lanes == 1) break;
     n_in = 2 * lanes;
     cur ^= 1;
   }
-  // window sums
-  int m_in = 1 << p.c, g = 0, k = 0;
-  const int sg = ilog2((uint32_t)p.S);
-  {
-    const int m_out = (m_in + p.S - 1) / p.S;
-    const int tot = m_out * p.W;
-    hipLaunchKernelGGL((k_wsum<CV, true>), dim3((tot + TB - 1) / TB), dim3(TB), 0, st, (const u32*)nullptr,
-                       L.buckets, L.hist, m_in, p.S, g, L.wA[0], L.wR[0], m_out, p.W);
-    m_in = m_out;
-    g += sg;
-  }
+  // first window-sum level: S buckets per lane, W * 2^c / S lanes (throughput-bound)
+  const int m_in = 1 << p.c;
+  const int m_out = (m_in + p.S - 1) / p.S;
+  const int tot = m_out * p.W;
+  hipLaunchKernelGGL((k_wsum<CT, true>), dim3((tot + TB - 1) / TB), dim3(TB), 0, st, (const u32*)nullptr,
+                     L.buckets, L.hist, m_in, p.S, 0, L.wA[0], L.wR[0], m_out, p.W);
+  OZK_HIP(hipGetLastError());
+  return OZK_OK;
+}
+
+// Tail phase: the latency-bound remainder (wave-cooperative window-sum levels, Horner over the
+// windows, affine normalisation).  Reads only the tail buffers; writes the wire-out result.
+template <class CV>
+static int var_msm_tail(int n, void* tail, size_t tail_bytes, void* d_out, hipStream_t st) {
+  using CT = CV;
+  const MsmPlan p = make_plan(n);
+  MsmLayout L;
+  L.m1 = (((size_t)1 << p.c) + p.S - 1) / p.S;
+  const size_t tneed = tail_layout<CV>(p, L, tail, tail_bytes);
+  if (tneed > tail_bytes) return fail(OZK_E_INVALID, "tail buffer too small: need %zu bytes, got %zu", tneed, tail_bytes);
+  int m_in = (int)L.m1, g = ilog2((uint32_t)p.S), k = 0;
   while (m_in > 1) {
-    const int m_out = (m_in + p.S - 1) / p.S;
+    const int m_out = (m_in + 63) / 64;
     const int tot = m_out * p.W;
-    hipLaunchKernelGGL((k_wsum<CV, false>), dim3((tot + TB - 1) / TB), dim3(TB), 0, st, L.wA[k], L.wR[k],
-                       (const u32*)nullptr, m_in, p.S, g, L.wA[k ^ 1], L.wR[k ^ 1], m_out, p.W);
+    hipLaunchKernelGGL((k_wsum_wave<CT>), dim3(tot), dim3(64), 0, st, L.wA[k], L.wR[k], m_in, g, L.wA[k ^ 1],
+                       L.wR[k ^ 1], m_out, p.W);
     m_in = m_out;
-    g += sg;
+    g += 6;
     k ^= 1;
   }
-  hipLaunchKernelGGL((k_finalize<CV>), dim3(1), dim3(64), 0, st, L.wA[k], p.W, p.c, (u32*)d_out);
+  hipLaunchKernelGGL((k_finalize<CT>), dim3(1), dim3(64), 0, st, L.wA[k], p.W, p.c, (u32*)d_out);
   OZK_HIP(hipGetLastError());
   return OZK_OK;
 }
 
 template <class CV>
+static size_t var_msm_tail_bytes(int n) {
+  const MsmPlan p = make_plan(n);
+  MsmLayout L;
+  L.m1 = (((size_t)1 << p.c) + p.S - 1) / p.S;
+  return tail_layout<CV>(p, L, nullptr, 0);
+}
+
+// head + tail on one stream, the tail buffers carved from the end of the workspace
+template <class CV>
+static int var_msm_dev(const void* d_bases, const void* d_scalars, int n, void* d_out, void* ws,
+                       size_t ws_bytes, hipStream_t st) {
+  const size_t main_bytes = make_layout<CV>(make_plan(n), nullptr, 0).bytes;
+  const size_t tb = var_msm_tail_bytes<CV>(n);
+  if (main_bytes + tb > ws_bytes)
+    return fail(OZK_E_INVALID, "workspace too small: need %zu bytes, got %zu", main_bytes + tb, ws_bytes);
+  uint8_t* tail = (uint8_t*)ws + main_bytes;
+  int rc = var_msm_head<CV>(d_bases, d_scalars, n, ws, main_bytes, tail, tb, st);
+  if (rc) return rc;
+  return var_msm_tail<CV>(n, tail, tb, d_out, st);
+}
+
+template <class CV>
 static size_t var_msm_ws_bytes(int n) {
+  return make_layout<CV>(make_plan(n), nullptr, 0).bytes + var_msm_tail_bytes<CV>(n);
+}
+template <class CV>
+static size_t var_msm_head_ws_bytes(int n) {
   return make_layout<CV>(make_plan(n), nullptr, 0).bytes;
 }
 
@@ -235,6 +297,31 @@ int ozk_var_msm_dev(const void* d_bases, const void* d_scalars, int32_t n, int32
 #else
   return fail(OZK_E_INVALID, "G2 not built");
 #endif
+}
+
+size_t ozk_var_msm_head_workspace_bytes(int32_t n, int32_t type) {
+  if (n <= 0) return 0;
+  return type == OZK_G1 ? var_msm_head_ws_bytes<G1Cfg>(n) : var_msm_head_ws_bytes<G2Cfg>(n);
+}
+size_t ozk_var_msm_tail_bytes(int32_t n, int32_t type) {
+  if (n <= 0) return 0;
+  return type == OZK_G1 ? var_msm_tail_bytes<G1Cfg>(n) : var_msm_tail_bytes<G2Cfg>(n);
+}
+int ozk_var_msm_head_dev(const void* d_bases, const void* d_scalars, int32_t n, int32_t type, void* d_workspace,
+                         size_t workspace_bytes, void* d_tail, size_t tail_bytes, void* stream) {
+  if (!d_bases || !d_scalars || !d_workspace || !d_tail) return fail(OZK_E_INVALID, "null pointer argument");
+  if (n <= 0 || n > (1 << 24)) return fail(OZK_E_INVALID, "batch_size %d out of range [1, 2^24]", n);
+  if (type == OZK_G1)
+    return var_msm_head<G1Cfg>(d_bases, d_scalars, n, d_workspace, workspace_bytes, d_tail, tail_bytes,
+                               (hipStream_t)stream);
+  return var_msm_head<G2Cfg>(d_bases, d_scalars, n, d_workspace, workspace_bytes, d_tail, tail_bytes,
+                             (hipStream_t)stream);
+}
+int ozk_var_msm_tail_dev(int32_t n, int32_t type, void* d_tail, size_t tail_bytes, void* d_out, void* stream) {
+  if (!d_tail || !d_out) return fail(OZK_E_INVALID, "null pointer argument");
+  if (n <= 0 || n > (1 << 24)) return fail(OZK_E_INVALID, "batch_size %d out of range [1, 2^24]", n);
+  if (type == OZK_G1) return var_msm_tail<G1Cfg>(n, d_tail, tail_bytes, d_out, (hipStream_t)stream);
+  return var_msm_tail<G2Cfg>(n, d_tail, tail_bytes, d_out, (hipStream_t)stream);
 }
 
 int ozk_var_msm_host(const uint8_t* bases, const uint8_t* scalars, int32_t n, int32_t type, int32_t task_id,

@@ -34,6 +34,56 @@ class VarMsmWorkspace:
         return self.out
 
 
+class VarMsmPipeline:
+    """Several device-resident MSMs in flight: heads (throughput-bound) run back to back on the
+    caller's stream and share ONE workspace; each tail (latency-bound: upper window-sum levels,
+    Horner, normalisation) runs on a side stream out of its own small tail buffer, overlapping the
+    next head.  This is how a prover issues its six independent MSMs.
+
+        pipe = VarMsmPipeline(n, depth=2)
+        t = pipe.submit(d_bases, d_scalars)      # returns a ticket
+        out = pipe.result(t)                     # makes the current stream wait for that tail
+    """
+
+    def __init__(self, n, type_=1, depth=2, device="cuda"):
+        L = _lib.load()
+        self.n, self.type, self.depth = n, type_, depth
+        self.ws_bytes = int(L.ozk_var_msm_head_workspace_bytes(n, type_))
+        self.tail_bytes = int(L.ozk_var_msm_tail_bytes(n, type_))
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
+        self.tails = [torch.empty(self.tail_bytes, dtype=torch.uint8, device=device) for _ in range(depth)]
+        self.outs = [torch.zeros(192 if type_ == 1 else 384, dtype=torch.uint8, device=device) for _ in range(depth)]
+        self.side = torch.cuda.Stream(device=device)
+        self.head_done = [torch.cuda.Event() for _ in range(depth)]
+        self.tail_done = [torch.cuda.Event() for _ in range(depth)]
+        self.count = 0
+
+    def submit(self, d_bases, d_scalars):
+        L = _lib.load()
+        slot = self.count % self.depth
+        main = torch.cuda.current_stream()
+        if self.count >= self.depth:
+            main.wait_event(self.tail_done[slot])      # the tail that last used this slot's buffers
+        _lib.check(L.ozk_var_msm_head_dev(_ptr(d_bases), _ptr(d_scalars), self.n, self.type, _ptr(self.ws),
+                                          self.ws_bytes, _ptr(self.tails[slot]), self.tail_bytes,
+                                          int(main.cuda_stream)))
+        self.head_done[slot].record(main)
+        self.side.wait_event(self.head_done[slot])
+        _lib.check(L.ozk_var_msm_tail_dev(self.n, self.type, _ptr(self.tails[slot]), self.tail_bytes,
+                                          _ptr(self.outs[slot]), int(self.side.cuda_stream)))
+        self.tail_done[slot].record(self.side)
+        self.count += 1
+        return self.count - 1
+
+    def result(self, ticket):
+        """Output tensor of `ticket` (valid until `depth` more submissions); the current stream
+        waits for its tail."""
+        assert self.count - ticket <= self.depth, "result buffer already reused"
+        slot = ticket % self.depth
+        torch.cuda.current_stream().wait_event(self.tail_done[slot])
+        return self.outs[slot]
+
+
 def gen_g1_bases(n, seed, device="cuda"):
     L = _lib.load()
     out = torch.empty(n * 96, dtype=torch.uint8, device=device)

@@ -58,12 +58,42 @@ def segreduce(bids, pts, L, buckets, written):
     return out_b, out_p, lanes
 
 
+RUN_MAX = 4  # small in the model so that both the short- and the long-run paths are exercised
+
+
+def runmerge(bids, pts, buckets, written):
+    """k_runmerge: every run of <= RUN_MAX adjacent slots is summed by the owner of its first slot."""
+    n = len(bids)
+    out = [NONE] * n
+    for x in range(n):
+        bx = bids[x]
+        if bx == NONE:
+            continue
+        s = e = x
+        while s > 0 and x - s < RUN_MAX and bids[s - 1] == bx:
+            s -= 1
+        while e + 1 < n and e - x < RUN_MAX and bids[e + 1] == bx:
+            e += 1
+        short = (x - s < RUN_MAX) and (e - x < RUN_MAX) and (e - s + 1 <= RUN_MAX)
+        if not short:
+            out[x] = bx
+        elif s == x:
+            acc = pts[s]
+            for q in range(s + 1, e + 1):
+                acc = G.add(acc, pts[q])
+            assert bx not in written
+            written.add(bx)
+            buckets[bx] = acc
+    return out
+
+
 def bucket_sums(entries, L1, LK):
     """entries: sorted list of (bid, point)."""
     buckets, written = {}, set()
     bids = [b for b, _ in entries]
     pts = [p for _, p in entries]
     bids, pts, lanes = segreduce(bids, pts, L1, buckets, written)
+    bids = runmerge(bids, pts, buckets, written)
     while True:
         bids, pts, lanes = segreduce(bids, pts, LK, buckets, written)
         if lanes == 1:
