@@ -10,9 +10,10 @@
 //
 // Pipeline (one launch each, all windows at once, no host round trips):
 //   convert   bases wire (Jacobian, canonical) -> affine Montgomery, 64 B records
-//   digits    scalars -> c-bit digits per window, histogram + rank by returning atomics
-//   scan      exclusive prefix sum of the W*2^c histogram
-//   scatter   counting-sort scatter of point indices by (window, digit)
+//   digits    scalars -> c-bit digits per window
+//   sort      two-level counting sort of the (window, digit) keys: hi part across blocks with
+//             per-block LDS counts + one global scan, lo part inside one block per coarse bin;
+//             LDS atomics only
 //   segreduce level 1: every lane takes L consecutive sorted entries and madd-accumulates
 //             runs of equal bucket id; complete runs go to the bucket array, runs cut by
 //             a chunk boundary become "partials" (2 slots per lane)
@@ -87,47 +88,185 @@ __global__ void __launch_bounds__(256) k_convert_bases(const u32* __restrict__ w
   IO::store_aff(q, o);
 }
 
-// ------------------------------------------------------------------ digits + histogram
-// digits[w*n + i] (u16), ranks[w*n + i] (u32): rank of entry among its bucket.
+// ------------------------------------------------------------------ digits
+// digits[w*n + i] (u16): the c-bit digit of scalar i in window w.  One pass over the scalars.
 __global__ void __launch_bounds__(256) k_digits(const u32* __restrict__ scalars, int n, int c, int W,
-                                                u32* __restrict__ hist, uint16_t* __restrict__ digits,
-                                                u32* __restrict__ ranks) {
+                                                uint16_t* __restrict__ digits) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = i < n;
+  if (i >= n) return;
   u32 s[8];
-  if (live) {
-    const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
-    const uint4 a = sp[0], b = sp[1];
-    s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w;
-    s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
-  } else {
-#pragma unroll
-    for (int k = 0; k < 8; k++) s[k] = 0;
+  const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
+  const uint4 a = sp[0], b = sp[1];
+  s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w;
+  s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+  for (int w = 0; w < W; w++) digits[(size_t)w * n + i] = (uint16_t)scalar_digit(s, w, c);
+}
+
+// ------------------------------------------------------------------ two-level counting sort
+// Sorting the (window, digit) keys with global returning atomics + a fully random scatter cost
+// 1.2 ms at 2^20 (profiles/r01_kernel_stats_v2_serial.csv).  Instead: split the digit into
+// hi (c - 8 bits) and lo (8 bits).
+//   sort1 count / scatter : a block takes SORT_CHUNK consecutive scalars of one window, counts
+//       / ranks them per hi value with LDS atomics; entries go to "coarse" bins (window, hi) as
+//       packed (index << 8 | lo) words — runs of ~16 consecutive words per bin and block.
+//   sort2 : one block per coarse bin: LDS histogram of lo, block scan -> bucket offsets and
+//       counts (written for EVERY bucket, so no memset), LDS-ranked scatter inside the bin's
+//       own few-KB window of the sorted arrays.
+// All atomics are LDS atomics; a wave whose live lanes share one key issues one.
+constexpr int SORT_CHUNK = 4096;
+constexpr int SORT_BLOCK = 256;
+
+// LDS atomic add of 1 with wave aggregation when every live lane has the same key
+__device__ __forceinline__ u32 lds_rank(u32* cnt, u32 key, bool live) {
+  const unsigned long long m = __ballot(live);
+  u32 r = 0;
+  if (m != 0ull) {
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    const u32 kl = __shfl(key, leader);
+    if (__all(!live || key == kl)) {
+      u32 base = 0;
+      if (lane == leader) base = atomicAdd(&cnt[kl], (u32)__popcll(m));
+      base = __shfl(base, leader);
+      r = base + (u32)__popcll(m & ((1ull << lane) - 1ull));
+    } else if (live) {
+      r = atomicAdd(&cnt[key], 1u);
+    }
   }
-  const int lane = threadIdx.x & 63;
-  for (int w = 0; w < W; w++) {
-    const u32 d = live ? scalar_digit(s, w, c) : 0u;
-    const bool nz = d != 0;
-    const unsigned long long m = __ballot(nz);
-    u32 rank = 0;
-    if (m != 0ull) {
-      // wave-aggregated atomic when every live digit in the wave is the same bucket
-      // (skewed inputs: Fp.random-style scalars put whole waves into one bucket)
-      const int leader = __ffsll((long long)m) - 1;
-      const u32 dl = __shfl(d, leader);
-      const bool same = __all(!nz || d == dl);
-      if (same) {
-        u32 base = 0;
-        if (lane == leader) base = atomicAdd(&hist[((u32)w << c) | dl], (u32)__popcll(m));
-        base = __shfl(base, leader);
-        rank = base + (u32)__popcll(m & ((1ull << lane) - 1ull));
-      } else if (nz) {
-        rank = atomicAdd(&hist[((u32)w << c) | d], 1u);
+  return r;
+}
+
+// C1[(w*NH + h)*nblk + blk] = number of non-zero digits with hi value h in this block's chunk
+__global__ void __launch_bounds__(SORT_BLOCK) k_sort1_count(const uint16_t* __restrict__ digits, int n, int lo_bits,
+                                                            int NH, int nblk, u32* __restrict__ C1) {
+  extern __shared__ u32 cnt[];
+  const int w = blockIdx.y, blk = blockIdx.x;
+  for (int h = threadIdx.x; h < NH; h += SORT_BLOCK) cnt[h] = 0;
+  __syncthreads();
+  const int i0 = blk * SORT_CHUNK;
+  constexpr int PER = SORT_CHUNK / SORT_BLOCK;
+  u32 dreg[PER];  // all loads first (independent, pipelined), then the LDS atomics
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    const int i = i0 + k * SORT_BLOCK + threadIdx.x;
+    dreg[k] = (i < n) ? digits[(size_t)w * n + i] : 0u;
+  }
+#pragma unroll
+  for (int k = 0; k < PER; k++) lds_rank(cnt, dreg[k] >> lo_bits, dreg[k] != 0);
+  __syncthreads();
+  for (int h = threadIdx.x; h < NH; h += SORT_BLOCK) C1[((size_t)w * NH + h) * nblk + blk] = cnt[h];
+}
+
+// coarse[P1[(w*NH+h)*nblk + blk] + rank] = (i << 8) | lo
+__global__ void __launch_bounds__(SORT_BLOCK) k_sort1_scatter(const uint16_t* __restrict__ digits, int n, int lo_bits,
+                                                              int NH, int nblk, const u32* __restrict__ P1,
+                                                              u32* __restrict__ coarse) {
+  extern __shared__ u32 cnt[];
+  const int w = blockIdx.y, blk = blockIdx.x;
+  for (int h = threadIdx.x; h < NH; h += SORT_BLOCK) cnt[h] = P1[((size_t)w * NH + h) * nblk + blk];
+  __syncthreads();
+  const int i0 = blk * SORT_CHUNK;
+  const u32 lo_mask = (1u << lo_bits) - 1u;
+  constexpr int PER = SORT_CHUNK / SORT_BLOCK;
+  u32 dreg[PER];
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    const int i = i0 + k * SORT_BLOCK + threadIdx.x;
+    dreg[k] = (i < n) ? digits[(size_t)w * n + i] : 0u;
+  }
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    const int i = i0 + k * SORT_BLOCK + threadIdx.x;
+    const bool live = dreg[k] != 0;
+    const u32 pos = lds_rank(cnt, dreg[k] >> lo_bits, live);
+    if (live) coarse[pos] = ((u32)i << 8) | (dreg[k] & lo_mask);
+  }
+}
+
+// one block per coarse bin (w, h): finishes the sort inside the bin
+__global__ void __launch_bounds__(SORT_BLOCK) k_sort2(const u32* __restrict__ coarse, const u32* __restrict__ P1,
+                                                      const u32* __restrict__ total, int c, int lo_bits, int NH,
+                                                      int nblk, int nbins, u32* __restrict__ hist,
+                                                      u32* __restrict__ sidx, u32* __restrict__ sbid) {
+  __shared__ u32 cnt[256];
+  __shared__ u32 cur[256];
+  __shared__ u32 wsum[SORT_BLOCK / 64];
+  const int bin = blockIdx.x;
+  const int NLO = 1 << lo_bits;
+  const u32 b0 = P1[(size_t)bin * nblk];
+  const u32 b1 = (bin + 1 < nbins) ? P1[(size_t)(bin + 1) * nblk] : *total;
+  const int w = bin / NH, h = bin - w * NH;
+  const u32 bucket0 = ((u32)w << c) | ((u32)h << lo_bits);
+  if (threadIdx.x < 256) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  // Bins of at most S2_TILE entries (every bin of a uniform input: 2^c/2^8 ... n/256 entries) are
+  // held in registers between the counting and the scattering sweep: one pipelined read of the
+  // bin, no second read.  Larger bins (skewed digits) stream twice.
+  constexpr int S2_PER = 24;
+  constexpr u32 S2_TILE = S2_PER * SORT_BLOCK;
+  const bool small = (b1 - b0) <= S2_TILE;
+  u32 vreg[S2_PER];
+  if (small) {
+#pragma unroll
+    for (int k = 0; k < S2_PER; k++) {
+      const u32 e = b0 + k * SORT_BLOCK + threadIdx.x;
+      vreg[k] = (e < b1) ? coarse[e] : 0xffffffffu;
+    }
+#pragma unroll
+    for (int k = 0; k < S2_PER; k++) {
+      const u32 e = b0 + k * SORT_BLOCK + threadIdx.x;
+      lds_rank(cnt, vreg[k] & 0xffu, e < b1);
+    }
+  } else {
+    for (u32 e = b0 + threadIdx.x; e - threadIdx.x < b1; e += SORT_BLOCK) {  // uniform trip count
+      const bool live = e < b1;
+      const u32 v = live ? coarse[e] : 0u;
+      lds_rank(cnt, v & 0xffu, live);
+    }
+  }
+  __syncthreads();
+  // exclusive scan of the NLO (<= 256) counts
+  const int t = threadIdx.x;
+  const u32 ct = (t < NLO) ? cnt[t] : 0u;
+  u32 incl = ct;
+  const int lane = t & 63;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const u32 x = __shfl_up(incl, o);
+    if (lane >= o) incl += x;
+  }
+  if (lane == 63) wsum[t >> 6] = incl;
+  __syncthreads();
+  u32 woff = 0;
+  for (int k = 0; k < (t >> 6); k++) woff += wsum[k];
+  const u32 excl = woff + incl - ct;
+  if (t < NLO) {
+    hist[bucket0 + t] = ct;
+    cur[t] = b0 + excl;
+  }
+  __syncthreads();
+  if (small) {
+#pragma unroll
+    for (int k = 0; k < S2_PER; k++) {
+      const u32 e = b0 + k * SORT_BLOCK + threadIdx.x;
+      const bool live = e < b1;
+      const u32 lo = vreg[k] & 0xffu;
+      const u32 pos = lds_rank(cur, lo, live);
+      if (live) {
+        sidx[pos] = vreg[k] >> 8;
+        sbid[pos] = bucket0 + lo;
       }
     }
-    if (live) {
-      digits[(size_t)w * n + i] = (uint16_t)d;
-      ranks[(size_t)w * n + i] = rank;
+  } else {
+    for (u32 e = b0 + threadIdx.x; e - threadIdx.x < b1; e += SORT_BLOCK) {
+      const bool live = e < b1;
+      const u32 v = live ? coarse[e] : 0u;
+      const u32 lo = v & 0xffu;
+      const u32 pos = lds_rank(cur, lo, live);
+      if (live) {
+        sidx[pos] = v >> 8;
+        sbid[pos] = bucket0 + lo;
+      }
     }
   }
 }
@@ -207,22 +346,6 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_final(const u32* __restrict
     if (base + k < (size_t)n) out[base + k] = run;
     run += v[k];
   }
-}
-
-// ------------------------------------------------------------------ scatter
-__global__ void __launch_bounds__(256) k_scatter(const uint16_t* __restrict__ digits,
-                                                 const u32* __restrict__ ranks,
-                                                 const u32* __restrict__ offs, int n, int c,
-                                                 u32* __restrict__ sidx, u32* __restrict__ sbid) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int w = blockIdx.y;
-  if (i >= n) return;
-  const u32 d = digits[(size_t)w * n + i];
-  if (d == 0) return;
-  const u32 b = ((u32)w << c) | d;
-  const u32 pos = offs[b] + ranks[(size_t)w * n + i];
-  sidx[pos] = (u32)i;
-  sbid[pos] = b;
 }
 
 // ------------------------------------------------------------------ segmented reduction

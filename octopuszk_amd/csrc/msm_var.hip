@@ -50,9 +50,11 @@ static MsmPlan make_plan(int n) {
 struct MsmLayout {
   // all device pointers into the workspace
   u32* aff;
-  u32 *hist, *offs, *blocksum, *total;  // total[0] = sorted entries, total[1] = live partial slots
+  u32 *hist, *C1, *P1, *blocksum, *total;  // total[0] = sorted entries, total[1] = live partial slots
   uint16_t* digits;
-  u32 *ranks, *sidx, *sbid;
+  u32 *coarse, *sidx, *sbid;
+  int lo_bits, NH, nblk;
+  size_t nC1;
   u32* buckets;
   u32 *slot_bid[2], *slot_pts[2], *slot_bid2;
   u32 *wA[2], *wR[2];
@@ -71,12 +73,17 @@ static MsmLayout make_layout(const MsmPlan& p, void* ws, size_t ws_bytes) {
   L.cap = (size_t)p.n * p.W;
   L.NB = (size_t)p.W << p.c;
   L.aff = b.take<u32>((size_t)p.n * IO::AFF_WORDS);
+  L.lo_bits = p.c < 8 ? p.c : 8;
+  L.NH = 1 << (p.c - L.lo_bits);
+  L.nblk = (p.n + SORT_CHUNK - 1) / SORT_CHUNK;
+  L.nC1 = (size_t)p.W * L.NH * L.nblk;
   L.hist = b.take<u32>(L.NB);
-  L.offs = b.take<u32>(L.NB);
-  L.blocksum = b.take<u32>(L.NB / (SCAN_BLOCK * SCAN_ITEMS) + 2);
+  L.C1 = b.take<u32>(L.nC1);
+  L.P1 = b.take<u32>(L.nC1);
+  L.blocksum = b.take<u32>(L.nC1 / (SCAN_BLOCK * SCAN_ITEMS) + 2);
   L.total = b.take<u32>(4);
   L.digits = b.take<uint16_t>(L.cap);
-  L.ranks = b.take<u32>(L.cap);
+  L.coarse = b.take<u32>(L.cap);
   L.sidx = b.take<u32>(L.cap);
   L.sbid = b.take<u32>(L.cap + 1);
   L.buckets = b.take<u32>(L.NB * IO::JAC_WORDS);
@@ -127,19 +134,24 @@ static int var_msm_head(const void* d_bases, const void* d_scalars, int n, void*
   const u32* bases = (const u32*)d_bases;
   const u32* scalars = (const u32*)d_scalars;
 
-  OZK_HIP(hipMemsetAsync(L.hist, 0, L.NB * sizeof(u32), st));
   OZK_HIP(hipMemsetAsync(L.total, 0, 4 * sizeof(u32), st));
   hipLaunchKernelGGL((k_convert_bases<CV>), dim3((n + TB - 1) / TB), dim3(TB), 0, st, bases, L.aff, n);
-  hipLaunchKernelGGL(k_digits, dim3((n + TB - 1) / TB), dim3(TB), 0, st, scalars, n, p.c, p.W, L.hist,
-                     L.digits, L.ranks);
-  // exclusive scan of the histogram -> bucket offsets, total entry count M
+  hipLaunchKernelGGL(k_digits, dim3((n + TB - 1) / TB), dim3(TB), 0, st, scalars, n, p.c, p.W, L.digits);
+  // two-level counting sort by (window, digit): per-block LDS counts of the hi part, one global
+  // exclusive scan, coarse scatter, then one block per coarse bin finishes by the lo part
+  const size_t lds1 = (size_t)L.NH * sizeof(u32);
+  hipLaunchKernelGGL(k_sort1_count, dim3(L.nblk, p.W), dim3(SORT_BLOCK), lds1, st, L.digits, n, L.lo_bits, L.NH,
+                     L.nblk, L.C1);
   const int items = SCAN_BLOCK * SCAN_ITEMS;
-  const int nb = (int)((L.NB + items - 1) / items);
-  hipLaunchKernelGGL(k_scan_blocksum, dim3(nb), dim3(SCAN_BLOCK), 0, st, L.hist, (int)L.NB, L.blocksum);
+  const int nb = (int)((L.nC1 + items - 1) / items);
+  hipLaunchKernelGGL(k_scan_blocksum, dim3(nb), dim3(SCAN_BLOCK), 0, st, L.C1, (int)L.nC1, L.blocksum);
   hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, L.blocksum, nb, L.total);
-  hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_BLOCK), 0, st, L.hist, (int)L.NB, L.blocksum, L.offs);
-  hipLaunchKernelGGL(k_scatter, dim3((n + TB - 1) / TB, p.W), dim3(TB), 0, st, L.digits, L.ranks, L.offs, n,
-                     p.c, L.sidx, L.sbid);
+  hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_BLOCK), 0, st, L.C1, (int)L.nC1, L.blocksum, L.P1);
+  hipLaunchKernelGGL(k_sort1_scatter, dim3(L.nblk, p.W), dim3(SORT_BLOCK), lds1, st, L.digits, n, L.lo_bits, L.NH,
+                     L.nblk, L.P1, L.coarse);
+  const int nbins = p.W * L.NH;
+  hipLaunchKernelGGL(k_sort2, dim3(nbins), dim3(SORT_BLOCK), 0, st, L.coarse, L.P1, L.total, p.c, L.lo_bits, L.NH,
+                     L.nblk, nbins, L.hist, L.sidx, L.sbid);
   // level 1 over the sorted entries
   size_t lanes = (L.cap + p.L1 - 1) / p.L1;
   const bool prof = g_prof.on && g_prof.created && g_prof.count < ProfState::MAXP;
