@@ -4,7 +4,12 @@
 //   coordinate  : CW = 8 (Fq) or 16 (Fq2: c0|c1) little-endian u32 words, value < 2^256
 //   affine base : x|y            = 2*CW words (64 B G1 / 128 B G2), canonical (< p);
 //                 x = y = 0 encodes the point at infinity
-//   Jacobian    : X|Y|Z          = 3*CW words (96 B / 192 B), each coordinate < 4p
+//   Jacobian    : X|Y|Z as UNPACKED 29-bit limbs, 9 (Fq) / 18 (Fq2) words per coordinate, record
+//                 padded to 28 / 56 words (112 B / 224 B): intermediate points (buckets, partial
+//                 slots, window-sum elements, fixed-base tables) are written and read a few times
+//                 by our own kernels only, so they skip the conditional subtractions + bit
+//                 packing a 256-bit record would need at every run end of the hot loop and keep
+//                 their lazy value bounds (the coordinate TYPES of the curve config)
 // wire in  (reference JNI input, VariableBaseMSM.java:221-228): 3*CW words, canonical,
 //          non-Montgomery, little-endian.
 // wire out (reference JNI output, VariableBaseMSM.cu:1655-1659): per Fq value 64 B LE,
@@ -33,6 +38,17 @@ struct ElemTraits<Fe<P, B>> {
     pack(reduce_to<64>(e), w);
 #pragma unroll
     for (int i = 0; i < 8; i++) p[i] = w[i];
+  }
+  static constexpr int RAW_WORDS = 9;
+  static OZK_HD Fe<P, B> load_raw(const u32* p) {
+    Fe<P, B> r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = p[i];
+    return r;
+  }
+  static OZK_HD void store_raw(const Fe<P, B>& e, u32* p) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) p[i] = e.l[i];
   }
   static OZK_HD Fe<P, B> from_wire(const u32* p) {
     u32 w[8];
@@ -75,7 +91,9 @@ struct CurveIO {
   using EA = typename CV::EA;
   static constexpr int CW = ElemTraits<EA>::WORDS;
   static constexpr int AFF_WORDS = 2 * CW;
-  static constexpr int JAC_WORDS = 3 * CW;
+  static constexpr int WIRE_JAC_WORDS = 3 * CW;             // JNI wire input point
+  static constexpr int RW = ElemTraits<EA>::RAW_WORDS;      // unpacked words per coordinate
+  static constexpr int JAC_WORDS = (3 * RW + 3) / 4 * 4;    // stored Jacobian record (16-B multiple)
 
   static OZK_HD Aff<EA> load_aff(const u32* p) {
     Aff<EA> q;
@@ -87,18 +105,19 @@ struct CurveIO {
     ElemTraits<EA>::store(q.x, p);
     ElemTraits<EA>::store(q.y, p + CW);
   }
-  // stored Jacobian coordinates are < 4p, which is within every EX/EY/EZ bound
+  // stored coordinates keep the bounds of EX / EY / EZ (every kernel of one pipeline uses the
+  // same curve config); an all-zero record is the point at infinity (Z = 0)
   static OZK_HD Jac<CV> load_jac(const u32* p) {
     Jac<CV> r;
-    r.X = ElemTraits<EX>::load(p);
-    r.Y = ElemTraits<EY>::load(p + CW);
-    r.Z = ElemTraits<EZ>::load(p + 2 * CW);
+    r.X = ElemTraits<EX>::load_raw(p);
+    r.Y = ElemTraits<EY>::load_raw(p + RW);
+    r.Z = ElemTraits<EZ>::load_raw(p + 2 * RW);
     return r;
   }
   static OZK_HD void store_jac(const Jac<CV>& r, u32* p) {
-    ElemTraits<EX>::store(r.X, p);
-    ElemTraits<EY>::store(r.Y, p + CW);
-    ElemTraits<EZ>::store(r.Z, p + 2 * CW);
+    ElemTraits<EX>::store_raw(r.X, p);
+    ElemTraits<EY>::store_raw(r.Y, p + RW);
+    ElemTraits<EZ>::store_raw(r.Z, p + 2 * RW);
   }
   static OZK_HD Jac<CV> jac_from_wire(const u32* p) {
     Jac<CV> r;

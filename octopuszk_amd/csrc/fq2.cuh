@@ -147,6 +147,17 @@ struct ElemTraits<Fe2<B>> {
     E1::store(e.c0, p);
     E1::store(e.c1, p + 8);
   }
+  static constexpr int RAW_WORDS = 18;
+  static OZK_HD Fe2<B> load_raw(const u32* p) {
+    Fe2<B> r;
+    r.c0 = E1::load_raw(p);
+    r.c1 = E1::load_raw(p + 9);
+    return r;
+  }
+  static OZK_HD void store_raw(const Fe2<B>& e, u32* p) {
+    E1::store_raw(e.c0, p);
+    E1::store_raw(e.c1, p + 9);
+  }
   static OZK_HD Fe2<B> from_wire(const u32* p) {
     Fe2<B> r;
     r.c0 = E1::from_wire(p);

@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(256) k_fb_norm(const u32* __restrict__ jac, in
 #pragma unroll
   for (int k = 0; k < FB_BATCH; k++) {
     if (k < cnt) {
-      const auto Z = reduce_to<32>(ElemTraits<typename CV::EZ>::load(jac + (size_t)(lo + k) * IO::JAC_WORDS + 2 * IO::CW));
+      const auto Z = reduce_to<32>(ElemTraits<typename CV::EZ>::load_raw(jac + (size_t)(lo + k) * IO::JAC_WORDS + 2 * IO::RW));
       if (!is_zero(Z)) run = EZ32(mul(run, Z));
     }
     prefix[k] = run;

@@ -251,8 +251,8 @@ static int var_msm_host(const uint8_t* bases, const uint8_t* scalars, int n, int
   using IO = CurveIO<CV>;
   int rc = select_device(task_id);
   if (rc) return rc;
-  const size_t base_bytes = (size_t)n * IO::JAC_WORDS * 4, sc_bytes = (size_t)n * 32;
-  const size_t out_bytes = (size_t)IO::JAC_WORDS * 8;
+  const size_t base_bytes = (size_t)n * IO::WIRE_JAC_WORDS * 4, sc_bytes = (size_t)n * 32;
+  const size_t out_bytes = (size_t)IO::WIRE_JAC_WORDS * 8;
   const size_t ws_bytes = var_msm_ws_bytes<CV>(n);
   uint8_t* d = nullptr;
   hipStream_t st = nullptr;
