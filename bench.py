@@ -93,10 +93,13 @@ def main():
         res, prev = None, None
         for _ in range(k):
             t = pipe.submit(bases, scalars)
+            if pipe.depth == 1:
+                res = finish(t)
+                continue
             if prev is not None:
                 res = finish(prev)
             prev = t
-        return finish(prev)
+        return finish(prev) if prev is not None else res
 
     def barrier():
         if world > 1:
