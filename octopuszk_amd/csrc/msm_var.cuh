@@ -494,6 +494,7 @@ __global__ void __launch_bounds__(256)
 k_wsum(const u32* __restrict__ A_in, const u32* __restrict__ R_in, const u32* __restrict__ hist,
        int m_in, int S, int g, u32* __restrict__ A_out, u32* __restrict__ R_out, int m_out, int W) {
   using IO = CurveIO<CV>;
+  if constexpr (!FIRSTLEVEL) __builtin_amdgcn_s_setprio(3);  // tail phase: see k_wsum_wave
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= m_out * W) return;
   const int w = t / m_out, j = t - w * m_out;
