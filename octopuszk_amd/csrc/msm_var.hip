@@ -41,7 +41,7 @@ static MsmPlan make_plan(int n) {
   p.LK = env_int("OZK_MSM_LK", 16);
   if (p.L1 < 2) p.L1 = 2;
   if (p.LK < 4) p.LK = 4;
-  int S = env_int("OZK_MSM_S", 8);
+  int S = env_int("OZK_MSM_S", 16);
   int sg = ilog2((uint32_t)(S < 2 ? 2 : S));
   p.S = 1 << sg;
   return p;
