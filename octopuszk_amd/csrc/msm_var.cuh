@@ -183,11 +183,159 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sort1_scatter(const uint16_t* __
   }
 }
 
+// Coarse bins above max(SORT_BIG, n/64) entries (skewed digits: the reference's own profiler inputs put half
+// of a window into one bucket) are not left to one block: k_sortbig_list enumerates them and cuts
+// them into SORTBIG_CHUNK-entry work items, k_sortbig_count / _scan / _scatter run the same
+// count - scan - ranked-scatter scheme over those items with a fixed grid.  With no big bin the
+// three kernels return at once.
+constexpr u32 SORT_BIG = 1u << 16;
+constexpr u32 SORTBIG_CHUNK = 1u << 13;
+constexpr int SORTBIG_MAXBINS = 1024;   // >= number of bins that can exceed SORT_BIG: cap / SORT_BIG
+struct BigBins {                        // device-resident work list
+  u32 n_big, n_items;
+  u32 bin[SORTBIG_MAXBINS], b0[SORTBIG_MAXBINS], size[SORTBIG_MAXBINS], first_item[SORTBIG_MAXBINS];
+};
+
+__global__ void __launch_bounds__(256) k_sortbig_list(const u32* __restrict__ P1, const u32* __restrict__ total,
+                                                      int nblk, int nbins, u32 big_thresh,
+                                                      BigBins* __restrict__ bb) {
+  __shared__ u32 n_big, n_items;
+  if (threadIdx.x == 0) n_big = n_items = 0;
+  __syncthreads();
+  for (int bin = threadIdx.x; bin < nbins; bin += blockDim.x) {
+    const u32 b0 = P1[(size_t)bin * nblk];
+    const u32 b1 = (bin + 1 < nbins) ? P1[(size_t)(bin + 1) * nblk] : *total;
+    if (b1 - b0 > big_thresh) {
+      const u32 k = atomicAdd(&n_big, 1u);
+      const u32 items = (b1 - b0 + SORTBIG_CHUNK - 1) / SORTBIG_CHUNK;
+      const u32 first = atomicAdd(&n_items, items);
+      if (k < (u32)SORTBIG_MAXBINS) {
+        bb->bin[k] = (u32)bin;
+        bb->b0[k] = b0;
+        bb->size[k] = b1 - b0;
+        bb->first_item[k] = first;
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // big_thresh >= n/64 bounds the number of big bins by 64 * W <= SORTBIG_MAXBINS
+    bb->n_big = n_big < (u32)SORTBIG_MAXBINS ? n_big : (u32)SORTBIG_MAXBINS;
+    bb->n_items = n_items;
+  }
+}
+
+// item -> (index r into the big-bin list, chunk k inside that bin)
+__device__ __forceinline__ bool sortbig_item(const BigBins* bb, u32 item, u32& r, u32& k) {
+  const u32 nb = bb->n_big;
+  for (u32 q = 0; q < nb; q++) {
+    const u32 f = bb->first_item[q];
+    const u32 items = (bb->size[q] + SORTBIG_CHUNK - 1) / SORTBIG_CHUNK;
+    if (item >= f && item < f + items) {
+      r = q;
+      k = item - f;
+      return true;
+    }
+  }
+  return false;
+}
+
+// T[item][lo] = count of lo in the item's chunk
+__global__ void __launch_bounds__(SORT_BLOCK) k_sortbig_count(const u32* __restrict__ coarse,
+                                                              const BigBins* __restrict__ bb, u32* __restrict__ T) {
+  __shared__ u32 cnt[256];
+  const u32 n_items = bb->n_items;
+  for (u32 item = blockIdx.x; item < n_items; item += gridDim.x) {
+    u32 r, k;
+    if (!sortbig_item(bb, item, r, k)) continue;
+    cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const u32 lo0 = bb->b0[r] + k * SORTBIG_CHUNK;
+    const u32 end = bb->b0[r] + bb->size[r];
+    const u32 hi0 = (lo0 + SORTBIG_CHUNK < end) ? lo0 + SORTBIG_CHUNK : end;
+    for (u32 e = lo0 + threadIdx.x; e - threadIdx.x < hi0; e += SORT_BLOCK) {
+      const bool live = e < hi0;
+      const u32 v = live ? coarse[e] : 0u;
+      lds_rank(cnt, v & 0xffu, live);
+    }
+    __syncthreads();
+    T[(size_t)item * 256 + threadIdx.x] = cnt[threadIdx.x];
+    __syncthreads();
+  }
+}
+
+// one block per big bin, lane = lo: bucket totals, bucket bases, per-item bases (in place in T)
+__global__ void __launch_bounds__(256) k_sortbig_scan(const BigBins* __restrict__ bb, u32* __restrict__ T, int c,
+                                                      int lo_bits, int NH, u32* __restrict__ hist) {
+  __shared__ u32 wsum[4];
+  const u32 r = blockIdx.x;
+  if (r >= bb->n_big || r >= (u32)SORTBIG_MAXBINS) return;
+  const u32 items = (bb->size[r] + SORTBIG_CHUNK - 1) / SORTBIG_CHUNK;
+  const u32 f = bb->first_item[r];
+  const int t = threadIdx.x;
+  u32 tot = 0;
+  for (u32 k = 0; k < items; k++) tot += T[(size_t)(f + k) * 256 + t];
+  // exclusive scan of tot over lo
+  u32 incl = tot;
+  const int lane = t & 63;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const u32 x = __shfl_up(incl, o);
+    if (lane >= o) incl += x;
+  }
+  if (lane == 63) wsum[t >> 6] = incl;
+  __syncthreads();
+  u32 woff = 0;
+  for (int q = 0; q < (t >> 6); q++) woff += wsum[q];
+  u32 run = bb->b0[r] + woff + incl - tot;
+  const int bin = (int)bb->bin[r];
+  const int w = bin / NH, h = bin - w * NH;
+  if (t < (1 << lo_bits)) hist[(((u32)w << c) | ((u32)h << lo_bits)) + t] = tot;
+  for (u32 k = 0; k < items; k++) {
+    const u32 cnt = T[(size_t)(f + k) * 256 + t];
+    T[(size_t)(f + k) * 256 + t] = run;
+    run += cnt;
+  }
+}
+
+__global__ void __launch_bounds__(SORT_BLOCK) k_sortbig_scatter(const u32* __restrict__ coarse,
+                                                                const BigBins* __restrict__ bb,
+                                                                const u32* __restrict__ T, int c, int lo_bits,
+                                                                int NH, u32* __restrict__ sidx,
+                                                                u32* __restrict__ sbid) {
+  __shared__ u32 cur[256];
+  const u32 n_items = bb->n_items;
+  for (u32 item = blockIdx.x; item < n_items; item += gridDim.x) {
+    u32 r, k;
+    if (!sortbig_item(bb, item, r, k)) continue;
+    cur[threadIdx.x] = T[(size_t)item * 256 + threadIdx.x];
+    __syncthreads();
+    const int bin = (int)bb->bin[r];
+    const int w = bin / NH, h = bin - w * NH;
+    const u32 bucket0 = ((u32)w << c) | ((u32)h << lo_bits);
+    const u32 lo0 = bb->b0[r] + k * SORTBIG_CHUNK;
+    const u32 end = bb->b0[r] + bb->size[r];
+    const u32 hi0 = (lo0 + SORTBIG_CHUNK < end) ? lo0 + SORTBIG_CHUNK : end;
+    for (u32 e = lo0 + threadIdx.x; e - threadIdx.x < hi0; e += SORT_BLOCK) {
+      const bool live = e < hi0;
+      const u32 v = live ? coarse[e] : 0u;
+      const u32 lo = v & 0xffu;
+      const u32 pos = lds_rank(cur, lo, live);
+      if (live) {
+        sidx[pos] = v >> 8;
+        sbid[pos] = bucket0 + lo;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // one block per coarse bin (w, h): finishes the sort inside the bin
 __global__ void __launch_bounds__(SORT_BLOCK) k_sort2(const u32* __restrict__ coarse, const u32* __restrict__ P1,
                                                       const u32* __restrict__ total, int c, int lo_bits, int NH,
-                                                      int nblk, int nbins, u32* __restrict__ hist,
-                                                      u32* __restrict__ sidx, u32* __restrict__ sbid) {
+                                                      int nblk, int nbins, u32 big_thresh,
+                                                      u32* __restrict__ hist, u32* __restrict__ sidx,
+                                                      u32* __restrict__ sbid) {
   __shared__ u32 cnt[256];
   __shared__ u32 cur[256];
   __shared__ u32 wsum[SORT_BLOCK / 64];
@@ -197,6 +345,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sort2(const u32* __restrict__ co
   const u32 b1 = (bin + 1 < nbins) ? P1[(size_t)(bin + 1) * nblk] : *total;
   const int w = bin / NH, h = bin - w * NH;
   const u32 bucket0 = ((u32)w << c) | ((u32)h << lo_bits);
+  if (b1 - b0 > big_thresh) return;  // split over many blocks by the k_sortbig_* kernels
   if (threadIdx.x < 256) cnt[threadIdx.x] = 0;
   __syncthreads();
   // Bins of at most S2_TILE entries (every bin of a uniform input: 2^c/2^8 ... n/256 entries) are

@@ -53,6 +53,9 @@ struct MsmLayout {
   u32 *hist, *C1, *P1, *blocksum, *total;  // total[0] = sorted entries, total[1] = live partial slots
   uint16_t* digits;
   u32 *coarse, *sidx, *sbid;
+  BigBins* bigbins;
+  u32* bigT;
+  size_t big_items_max;
   int lo_bits, NH, nblk;
   size_t nC1;
   u32* buckets;
@@ -84,6 +87,9 @@ static MsmLayout make_layout(const MsmPlan& p, void* ws, size_t ws_bytes) {
   L.total = b.take<u32>(4);
   L.digits = b.take<uint16_t>(L.cap);
   L.coarse = b.take<u32>(L.cap);
+  L.bigbins = b.take<BigBins>(1);
+  L.big_items_max = L.cap / SORTBIG_CHUNK + SORTBIG_MAXBINS + 1;
+  L.bigT = b.take<u32>(L.big_items_max * 256);
   L.sidx = b.take<u32>(L.cap);
   L.sbid = b.take<u32>(L.cap + 1);
   L.buckets = b.take<u32>(L.NB * IO::JAC_WORDS);
@@ -150,8 +156,16 @@ static int var_msm_head(const void* d_bases, const void* d_scalars, int n, void*
   hipLaunchKernelGGL(k_sort1_scatter, dim3(L.nblk, p.W), dim3(SORT_BLOCK), lds1, st, L.digits, n, L.lo_bits, L.NH,
                      L.nblk, L.P1, L.coarse);
   const int nbins = p.W * L.NH;
+  const u32 big_thresh = (u32)(n / 64) > SORT_BIG ? (u32)(n / 64) : SORT_BIG;
   hipLaunchKernelGGL(k_sort2, dim3(nbins), dim3(SORT_BLOCK), 0, st, L.coarse, L.P1, L.total, p.c, L.lo_bits, L.NH,
-                     L.nblk, nbins, L.hist, L.sidx, L.sbid);
+                     L.nblk, nbins, big_thresh, L.hist, L.sidx, L.sbid);
+  // bins above SORT_BIG entries (skewed digits), split over a fixed grid; no-ops otherwise
+  hipLaunchKernelGGL(k_sortbig_list, dim3(1), dim3(256), 0, st, L.P1, L.total, L.nblk, nbins, big_thresh, L.bigbins);
+  hipLaunchKernelGGL(k_sortbig_count, dim3(1024), dim3(SORT_BLOCK), 0, st, L.coarse, L.bigbins, L.bigT);
+  hipLaunchKernelGGL(k_sortbig_scan, dim3(SORTBIG_MAXBINS), dim3(256), 0, st, L.bigbins, L.bigT, p.c, L.lo_bits, L.NH,
+                     L.hist);
+  hipLaunchKernelGGL(k_sortbig_scatter, dim3(1024), dim3(SORT_BLOCK), 0, st, L.coarse, L.bigbins, L.bigT, p.c,
+                     L.lo_bits, L.NH, L.sidx, L.sbid);
   // level 1 over the sorted entries
   size_t lanes = (L.cap + p.L1 - 1) / p.L1;
   const bool prof = g_prof.on && g_prof.created && g_prof.count < ProfState::MAXP;

@@ -220,3 +220,22 @@ def test_pipelined_equals_serial():
         prev = t
     got.append(bytes(pipe.result(prev).cpu().numpy()))
     assert got == serial and len(set(serial)) == 5
+
+
+def test_g1_profiler_shaped_full_size():
+    """VariableBaseMSMProfiling.java:19-31 at 2^20: ONE base repeated, Fp.random scalars (64-bit or
+    r - 64-bit): half of every high window lands in one bucket (giant coarse bins, long runs)."""
+    import numpy as np
+    import torch
+    from octopuszk_amd import device as dev
+    n = 1 << 20
+    rng = np.random.default_rng(10)
+    lows = rng.integers(0, 1 << 63, size=n, dtype=np.uint64)
+    neg = rng.integers(0, 2, size=n).astype(bool)
+    vals = [(o.R - int(v)) if ng else int(v) for v, ng in zip(lows, neg)]
+    sc = np.frombuffer(b"".join(v.to_bytes(32, "little") for v in vals), dtype=np.uint8).copy()
+    base = o.G1.to_affine(o.G1.mul(o.G1.one, 987654321))
+    bases = np.frombuffer(o.g1_to_wire(base) * n, dtype=np.uint8).copy()
+    out = dev.VarMsmWorkspace(n, 1).run(torch.from_numpy(bases).cuda(), torch.from_numpy(sc).cuda())
+    torch.cuda.synchronize()
+    assert bytes(out.cpu().numpy()) == o.g1_out_le(o.G1.to_affine(o.G1.mul(base, sum(vals) % o.R)))
