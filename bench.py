@@ -85,8 +85,19 @@ def main():
     from octopuszk_amd import distributed as ozk_dist
 
     def finish(ticket):
-        # the step's result; for N > 1: RCCL all-gather of the 192-B partials + HIP point sum
-        return ozk_dist.distributed_var_msm(lambda: pipe.result(ticket), dev.points_sum, 1)
+        # the step's result; for N > 1: RCCL all-gather of the 192-B partials + HIP point sum.
+        # Issued on the pipeline's side stream (behind the tail it consumes), so the single-lane
+        # point sum does not sit between two heads on the main stream.
+        if world == 1:
+            return pipe.result(ticket)
+        with torch.cuda.stream(pipe.side):
+            out = ozk_dist.distributed_var_msm(lambda: pipe.result(ticket), dev.points_sum, 1)
+            done = torch.cuda.Event()
+            done.record(pipe.side)
+        finish.last_event = done
+        return out
+
+    finish.last_event = None
 
     def run_steps(k):
         """k complete MSMs; step i's tail overlaps step i+1's head (args.in_flight > 1)."""
@@ -102,6 +113,7 @@ def main():
         return finish(prev) if prev is not None else res
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
