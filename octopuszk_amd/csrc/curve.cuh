@@ -119,6 +119,32 @@ struct CurveIO {
     ElemTraits<EY>::store_raw(r.Y, p + RW);
     ElemTraits<EZ>::store_raw(r.Z, p + 2 * RW);
   }
+  // Tagged point record for buckets and partial slots (REC_WORDS words): level 1 dumps its XYZZ
+  // accumulator as it is (a run end is a divergent branch of the hot loop: no arithmetic there),
+  // later kernels store Jacobian points; readers convert XYZZ with two multiplications.
+  static constexpr int REC_TAG = 4 * RW;                        // word index of the format tag
+  static constexpr int REC_WORDS = (4 * RW + 1 + 3) / 4 * 4;    // 40 (G1) / 76 (G2) words
+  static constexpr u32 TAG_XYZZ = 0, TAG_JAC = 1;
+  static OZK_HD void store_rec_xyzz(const Xyzz<CV>& a, u32* p) {
+    ElemTraits<typename CV::XX>::store_raw(a.X, p);
+    ElemTraits<typename CV::XY>::store_raw(a.Y, p + RW);
+    ElemTraits<typename CV::XZZ>::store_raw(a.ZZ, p + 2 * RW);
+    ElemTraits<typename CV::XZZZ>::store_raw(a.ZZZ, p + 3 * RW);
+    p[REC_TAG] = TAG_XYZZ;
+  }
+  static OZK_HD void store_rec_jac(const Jac<CV>& r, u32* p) {
+    store_jac(r, p);
+    p[REC_TAG] = TAG_JAC;
+  }
+  static OZK_HD Jac<CV> load_rec(const u32* p) {
+    if (p[REC_TAG] == TAG_JAC) return load_jac(p);
+    Xyzz<CV> a;
+    a.X = ElemTraits<typename CV::XX>::load_raw(p);
+    a.Y = ElemTraits<typename CV::XY>::load_raw(p + RW);
+    a.ZZ = ElemTraits<typename CV::XZZ>::load_raw(p + 2 * RW);
+    a.ZZZ = ElemTraits<typename CV::XZZZ>::load_raw(p + 3 * RW);
+    return xyzz_to_jac(a);
+  }
   static OZK_HD Jac<CV> jac_from_wire(const u32* p) {
     Jac<CV> r;
     r.X = ElemTraits<EX>::from_wire(p);

@@ -200,6 +200,10 @@ struct G2Cfg {
   using EY = Fe2<112>;
   using EZ = Fe2<112>;
   using EA = Fe2<17>;
+  using XX = Fe2<144>;   // sqr - (PPP + 2Q) < 2p + 7p
+  using XY = Fe2<80>;    // mul - mul < 2p + 3p
+  using XZZ = Fe2<32>;
+  using XZZZ = Fe2<32>;
 };
 
 }  // namespace ozk

@@ -14,8 +14,8 @@
 //   sort      two-level counting sort of the (window, digit) keys: hi part across blocks with
 //             per-block LDS counts + one global scan, lo part inside one block per coarse bin;
 //             LDS atomics only
-//   segreduce level 1: every lane takes L consecutive sorted entries and madd-accumulates
-//             runs of equal bucket id; complete runs go to the bucket array, runs cut by
+//   segreduce level 1: every lane takes L consecutive sorted entries and accumulates runs of
+//             equal bucket id with XYZZ mixed additions (8M + 2S); complete runs go to the bucket array, runs cut by
 //             a chunk boundary become "partials" (2 slots per lane)
 //             level >= 2: same scheme over the partial slots with Jacobian adds, until
 //             one lane remains — load-balanced for ANY digit distribution (a bucket
@@ -505,6 +505,35 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_final(const u32* __restrict
 // 2t+1), so pieces of one bucket stay adjacent in slot order and the next level can apply
 // the same rule.  Unused slots carry BID_NONE.  Each bucket is written exactly once, at
 // the level where its last pieces meet.
+// accumulator of one run: XYZZ + mixed additions over affine bases at level 1, Jacobian +
+// Jacobian additions over partial slots at the higher levels
+template <class CV, bool FIRST>
+struct RunAcc;
+template <class CV>
+struct RunAcc<CV, true> {
+  using IO = CurveIO<CV>;
+  Xyzz<CV> a;
+  __device__ __forceinline__ void start(const u32* pts, const u32* idx, long long p) {
+    a = xyzz_from_affine<CV>(IO::load_aff(pts + (size_t)idx[p] * IO::AFF_WORDS));
+  }
+  __device__ __forceinline__ void add(const u32* pts, const u32* idx, long long p) {
+    a = xyzz_madd(a, IO::load_aff(pts + (size_t)idx[p] * IO::AFF_WORDS));
+  }
+  __device__ __forceinline__ void store(u32* dst) const { IO::store_rec_xyzz(a, dst); }
+};
+template <class CV>
+struct RunAcc<CV, false> {
+  using IO = CurveIO<CV>;
+  Jac<CV> a;
+  __device__ __forceinline__ void start(const u32* pts, const u32*, long long p) {
+    a = IO::load_rec(pts + (size_t)p * IO::REC_WORDS);
+  }
+  __device__ __forceinline__ void add(const u32* pts, const u32*, long long p) {
+    a = jac_add(a, IO::load_rec(pts + (size_t)p * IO::REC_WORDS));
+  }
+  __device__ __forceinline__ void store(u32* dst) const { IO::store_rec_jac(a, dst); }
+};
+
 template <class CV, bool FIRST>
 __global__ void __launch_bounds__(256)
 k_segreduce(const u32* __restrict__ bid_in, const u32* __restrict__ idx_in,
@@ -515,7 +544,7 @@ k_segreduce(const u32* __restrict__ bid_in, const u32* __restrict__ idx_in,
   using IO = CurveIO<CV>;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_lanes) return;
-  // levels >= 2: d_count is the number of partial slots still alive after the pair merge;
+  // levels >= 2: d_count is the number of partial slots still alive after the run merge;
   // 0 means every bucket is already complete and the level has nothing to do
   if (!FIRST && *d_count == 0) return;
   const long long n_in = FIRST ? (long long)(*d_count) : (long long)n_in_static;
@@ -536,48 +565,38 @@ k_segreduce(const u32* __restrict__ bid_in, const u32* __restrict__ idx_in,
     const bool cf = (e < n_in) && (bid_in[e] == last_bid) && (last_bid != BID_NONE);
     u32 cur = BID_NONE;
     bool cur_cb = false;
-    Jac<CV> acc = jac_infinity<CV>();
+    RunAcc<CV, FIRST> acc;
     for (long long p = s; p < e; p++) {
       const u32 b = bid_in[p];
       if (b != cur) {
         if (cur != BID_NONE) {  // run [.., p) ended inside the chunk
           if (cur_cb) {
             head_bid = cur;
-            IO::store_jac(acc, pts_out + (size_t)(2 * (size_t)t) * IO::JAC_WORDS);
+            acc.store(pts_out + (size_t)(2 * (size_t)t) * IO::REC_WORDS);
           } else {
-            IO::store_jac(acc, buckets + (size_t)cur * IO::JAC_WORDS);
+            acc.store(buckets + (size_t)cur * IO::REC_WORDS);
           }
         }
         cur = b;
         cur_cb = (p == s) && cb;
-        if (b != BID_NONE) {
-          if constexpr (FIRST) {
-            acc = from_affine<CV>(IO::load_aff(pts_in + (size_t)idx_in[p] * IO::AFF_WORDS));
-          } else {
-            acc = IO::load_jac(pts_in + (size_t)p * IO::JAC_WORDS);
-          }
-        }
+        if (b != BID_NONE) acc.start(pts_in, idx_in, p);
       } else if (b != BID_NONE) {
-        if constexpr (FIRST) {
-          acc = jac_madd(acc, IO::load_aff(pts_in + (size_t)idx_in[p] * IO::AFF_WORDS));
-        } else {
-          acc = jac_add(acc, IO::load_jac(pts_in + (size_t)p * IO::JAC_WORDS));
-        }
+        acc.add(pts_in, idx_in, p);
       }
     }
     if (cur != BID_NONE) {  // last run of the chunk
       if (cur_cb) {
         head_bid = cur;
-        IO::store_jac(acc, pts_out + (size_t)(2 * (size_t)t) * IO::JAC_WORDS);
+        acc.store(pts_out + (size_t)(2 * (size_t)t) * IO::REC_WORDS);
         if (cf) {  // cut on both sides: neutral element keeps the pieces adjacent
           tail_bid = cur;
-          IO::store_jac(jac_infinity<CV>(), pts_out + (size_t)(2 * (size_t)t + 1) * IO::JAC_WORDS);
+          IO::store_rec_jac(jac_infinity<CV>(), pts_out + (size_t)(2 * (size_t)t + 1) * IO::REC_WORDS);
         }
       } else if (cf) {
         tail_bid = cur;
-        IO::store_jac(acc, pts_out + (size_t)(2 * (size_t)t + 1) * IO::JAC_WORDS);
+        acc.store(pts_out + (size_t)(2 * (size_t)t + 1) * IO::REC_WORDS);
       } else {
-        IO::store_jac(acc, buckets + (size_t)cur * IO::JAC_WORDS);
+        acc.store(buckets + (size_t)cur * IO::REC_WORDS);
       }
     }
   }
@@ -614,9 +633,9 @@ k_runmerge(const u32* __restrict__ bid_in, const u32* __restrict__ pts, int n_sl
       if (!is_short) {
         out = bx;
       } else if (s == x) {  // owner of the run: sum it
-        Jac<CV> acc = IO::load_jac(pts + (size_t)s * IO::JAC_WORDS);
-        for (int q = s + 1; q <= e; q++) acc = jac_add(acc, IO::load_jac(pts + (size_t)q * IO::JAC_WORDS));
-        IO::store_jac(acc, buckets + (size_t)bx * IO::JAC_WORDS);
+        Jac<CV> acc = IO::load_rec(pts + (size_t)s * IO::REC_WORDS);
+        for (int q = s + 1; q <= e; q++) acc = jac_add(acc, IO::load_rec(pts + (size_t)q * IO::REC_WORDS));
+        IO::store_rec_jac(acc, buckets + (size_t)bx * IO::REC_WORDS);
       }
     }
     bid_out[x] = out;
@@ -655,7 +674,7 @@ k_wsum(const u32* __restrict__ A_in, const u32* __restrict__ R_in, const u32* __
   for (int e = hi - 1; e >= lo; e--) {
     if constexpr (FIRSTLEVEL) {
       // buckets no entry was sorted into were never written: treat as infinity
-      if (hist[base + e] != 0) run = jac_add(run, IO::load_jac(R_in + (base + e) * IO::JAC_WORDS));
+      if (hist[base + e] != 0) run = jac_add(run, IO::load_rec(R_in + (base + e) * IO::REC_WORDS));
     } else {
       run = jac_add(run, IO::load_jac(R_in + (base + e) * IO::JAC_WORDS));
     }

@@ -92,16 +92,16 @@ static MsmLayout make_layout(const MsmPlan& p, void* ws, size_t ws_bytes) {
   L.bigT = b.take<u32>(L.big_items_max * 256);
   L.sidx = b.take<u32>(L.cap);
   L.sbid = b.take<u32>(L.cap + 1);
-  L.buckets = b.take<u32>(L.NB * IO::JAC_WORDS);
+  L.buckets = b.take<u32>(L.NB * IO::REC_WORDS);
   const size_t T1 = (L.cap + p.L1 - 1) / p.L1;
   L.slots0 = 2 * T1;
   const size_t T2 = (L.slots0 + p.LK - 1) / p.LK;
   L.slots1 = 2 * T2;
   L.slot_bid[0] = b.take<u32>(L.slots0);
-  L.slot_pts[0] = b.take<u32>(L.slots0 * IO::JAC_WORDS);
+  L.slot_pts[0] = b.take<u32>(L.slots0 * IO::REC_WORDS);
   L.slot_bid2 = b.take<u32>(L.slots0);
   L.slot_bid[1] = b.take<u32>(L.slots1);
-  L.slot_pts[1] = b.take<u32>(L.slots1 * IO::JAC_WORDS);
+  L.slot_pts[1] = b.take<u32>(L.slots1 * IO::REC_WORDS);
   L.m1 = (((size_t)1 << p.c) + p.S - 1) / p.S;
   b.take<u32>(64);
   L.bytes = b.off;

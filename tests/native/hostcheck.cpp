@@ -53,6 +53,7 @@ static void store_jac(const Jac<J1>& p, u32* w) {
 extern "C" void hc_g1_op(int op, const u32* pw, const u32* qw, int k, u32* out) {
   Jac<J1> p = load_jac(pw), q = load_jac(qw), r;
   Aff<A1> qa; qa.x = A1(reduce_to<17>(q.X)); qa.y = A1(reduce_to<17>(q.Y));
+  if (is_zero(q.Z)) { qa.x = A1(el_zero(qa.x)); qa.y = A1(el_zero(qa.x)); }  // (0, 0) encodes infinity
   switch (op) {
     case 0: r = jac_add(p, q); break;
     case 1: r = jac_dbl(p); break;
@@ -60,6 +61,14 @@ extern "C" void hc_g1_op(int op, const u32* pw, const u32* qw, int k, u32* out) 
     case 3: r = p; for (int i = 0; i < k; i++) r = jac_madd(r, qa); break;
     case 4: r = p; for (int i = 0; i < k; i++) r = jac_add(r, q); break;
     case 5: r = p; for (int i = 0; i < k; i++) r = jac_dbl(r); break;
+    case 7: {  // XYZZ accumulator: affine(P) then k mixed additions of affine(Q), back to Jacobian
+      Aff<A1> pa; pa.x = A1(reduce_to<17>(p.X)); pa.y = A1(reduce_to<17>(p.Y));
+      if (is_zero(p.Z)) { pa.x = A1(el_zero(pa.x)); pa.y = A1(el_zero(pa.x)); }
+      Xyzz<J1> a = xyzz_from_affine<J1>(pa);
+      for (int i = 0; i < k; i++) a = xyzz_madd(a, qa);
+      r = xyzz_to_jac(a);
+      break;
+    }
     default: r = p;
   }
   store_jac(r, out);
@@ -85,6 +94,7 @@ extern "C" void hc_g2_op(int op, const u32* pw, const u32* qw, int k, u32* out) 
   using IO = CurveIO<J2>;
   Jac<J2> p = IO::jac_from_wire(pw), q = IO::jac_from_wire(qw), r;
   Aff<J2::EA> qa; qa.x = J2::EA(reduce_to<17>(q.X)); qa.y = J2::EA(reduce_to<17>(q.Y));
+  if (is_zero(q.Z)) { qa.x = J2::EA(el_zero(qa.x)); qa.y = J2::EA(el_zero(qa.x)); }
   switch (op) {
     case 0: r = jac_add(p, q); break;
     case 1: r = jac_dbl(p); break;
@@ -92,6 +102,14 @@ extern "C" void hc_g2_op(int op, const u32* pw, const u32* qw, int k, u32* out) 
     case 3: r = p; for (int i = 0; i < k; i++) r = jac_madd(r, qa); break;
     case 4: r = p; for (int i = 0; i < k; i++) r = jac_add(r, q); break;
     case 5: r = p; for (int i = 0; i < k; i++) r = jac_dbl(r); break;
+    case 7: {
+      Aff<J2::EA> pa; pa.x = J2::EA(reduce_to<17>(p.X)); pa.y = J2::EA(reduce_to<17>(p.Y));
+      if (is_zero(p.Z)) { pa.x = J2::EA(el_zero(pa.x)); pa.y = J2::EA(el_zero(pa.x)); }
+      Xyzz<J2> a = xyzz_from_affine<J2>(pa);
+      for (int i = 0; i < k; i++) a = xyzz_madd(a, qa);
+      r = xyzz_to_jac(a);
+      break;
+    }
     default: r = p;
   }
   ElemTraits<J2::EX>::to_wire(r.X, out);

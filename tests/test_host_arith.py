@@ -111,6 +111,13 @@ def test_g1_group_law(hc):
     assert G.equals(g1_op(hc, 5, P, P, 64), G.mul(P, 1 << 64))
     # repeated base: P + P + P ... hits the doubling branch on the first step
     assert G.equals(g1_op(hc, 3, Pa, Pa, 5), G.mul(P, 6))
+    # XYZZ accumulator (the hot loop's coordinates): chains, doubling on the first step, cancellation
+    assert G.equals(g1_op(hc, 7, Pa, aff[1], 200), G.add(P, G.mul(aff[1], 200)))
+    assert G.equals(g1_op(hc, 7, Pa, Pa, 5), G.mul(P, 6))
+    assert G.is_zero(g1_op(hc, 7, Pa, G.negate(Pa), 1))
+    assert G.equals(g1_op(hc, 7, Pa, G.negate(Pa), 2), G.negate(P))
+    assert G.equals(g1_op(hc, 7, G.zero, aff[2], 3), G.mul(aff[2], 3))
+    assert G.equals(g1_op(hc, 7, Pa, G.zero, 4), P)
     # CurvesTest.java:27-82 identities on the HIP group law
     a = pts[3]
     assert G.equals(g1_op(hc, 0, G.mul(a, 76749407), G.mul(a, 44410867)), G.mul(a, 121160274))
@@ -174,3 +181,6 @@ def test_g2_group_law(hc):
     assert G.equals(g2_op(hc, 3, P, aff[1], 100), G.add(P, G.mul(aff[1], 100)))
     assert G.equals(g2_op(hc, 4, P, pts[2], 50), G.add(P, G.mul(pts[2], 50)))
     assert G.equals(g2_op(hc, 5, P, P, 40), G.mul(P, 1 << 40))
+    assert G.equals(g2_op(hc, 7, Pa, aff[1], 60), G.add(P, G.mul(aff[1], 60)))
+    assert G.equals(g2_op(hc, 7, Pa, Pa, 3), G.mul(P, 4))
+    assert G.is_zero(g2_op(hc, 7, Pa, G.negate(Pa), 1))
