@@ -238,7 +238,7 @@ static int var_msm_tail(int n, void* tail, size_t tail_bytes, void* d_out, hipSt
     g += 6;
     k ^= 1;
   }
-  hipLaunchKernelGGL((k_finalize<CT>), dim3(1), dim3(64), 0, st, L.wA[k], p.W, p.c, (u32*)d_out);
+  hipLaunchKernelGGL((k_finalize<CT>), dim3(1), dim3(256), 0, st, L.wA[k], p.W, p.c, (u32*)d_out);
   OZK_HIP(hipGetLastError());
   return OZK_OK;
 }
