@@ -74,6 +74,21 @@ int ozk_var_msm_dev(const void* d_bases, const void* d_scalars, int32_t n, int32
  * normalisation; a few lanes busy for ~2 ms) and reads nothing but `d_tail`.  Running the tail
  * on a second stream lets the next MSM's head (which may reuse the same workspace) overlap
  * it.  ozk_var_msm_dev == head + tail on one stream. */
+/* The head itself has two stages that stress different units — SORT (base conversion, digits,
+ * counting sort: HBM / LDS) and ACCUMULATE (bucket accumulation ... first window-sum level:
+ * vector ALU) — so a caller may pipeline three stages (sort of MSM k+2 | accumulate of k+1 |
+ * tail of k).  The hand-off between them is the "sorted set" (double-buffer it); sort and
+ * accumulate each have private scratch.  ozk_var_msm_head_dev == sort + accumulate.  (On
+ * MI355X the two-stage head | tail pipeline measured faster — 398 vs 348 Mscalar-mul/s at 2^20 —
+ * because the sort's LDS traffic slows the co-running accumulation more than it hides.) */
+int ozk_var_msm_stage_bytes(int32_t n, int32_t type, size_t* sorted_bytes, size_t* sort_ws_bytes,
+                            size_t* accum_ws_bytes);
+int ozk_var_msm_sort_dev(const void* d_bases, const void* d_scalars, int32_t n, int32_t type,
+                         void* d_sorted, size_t sorted_bytes, void* d_sort_ws, size_t sort_ws_bytes,
+                         void* stream);
+int ozk_var_msm_accum_dev(int32_t n, int32_t type, void* d_sorted, size_t sorted_bytes,
+                          void* d_accum_ws, size_t accum_ws_bytes, void* d_tail, size_t tail_bytes,
+                          void* stream);
 size_t ozk_var_msm_head_workspace_bytes(int32_t n, int32_t type);
 size_t ozk_var_msm_tail_bytes(int32_t n, int32_t type);
 int ozk_var_msm_head_dev(const void* d_bases, const void* d_scalars, int32_t n, int32_t type,

@@ -68,44 +68,67 @@ struct MsmLayout {
   size_t m1;    // wsum elements per window after the first level
 };
 
+// Three regions, so that a caller can pipeline three stages of consecutive MSMs:
+//   sorted set   : affine bases, bucket counts, sorted (index, bucket id) arrays, counters —
+//                  the hand-off from the SORT stage to the ACCUMULATE stage (double-buffer it)
+//   sort scratch : digits, per-block counts and their scan, coarse bins, big-bin work list
+//   accum scratch: bucket records and partial slots
+struct RegionBytes {
+  size_t sorted, sort_ws, accum_ws;
+};
 template <class CV>
-static MsmLayout make_layout(const MsmPlan& p, void* ws, size_t ws_bytes) {
+static MsmLayout make_layout3(const MsmPlan& p, void* sorted, void* sort_ws, void* accum_ws, RegionBytes* rb) {
   using IO = CurveIO<CV>;
   MsmLayout L;
-  Bump b(ws, ws_bytes);
   L.cap = (size_t)p.n * p.W;
   L.NB = (size_t)p.W << p.c;
-  L.aff = b.take<u32>((size_t)p.n * IO::AFF_WORDS);
   L.lo_bits = p.c < 8 ? p.c : 8;
   L.NH = 1 << (p.c - L.lo_bits);
   L.nblk = (p.n + SORT_CHUNK - 1) / SORT_CHUNK;
   L.nC1 = (size_t)p.W * L.NH * L.nblk;
-  L.hist = b.take<u32>(L.NB);
+  Bump a(sorted, ~(size_t)0);
+  L.aff = a.take<u32>((size_t)p.n * IO::AFF_WORDS);
+  L.hist = a.take<u32>(L.NB);
+  L.total = a.take<u32>(4);
+  L.sidx = a.take<u32>(L.cap);
+  L.sbid = a.take<u32>(L.cap + 1);
+  a.take<u32>(64);
+  Bump b(sort_ws, ~(size_t)0);
   L.C1 = b.take<u32>(L.nC1);
   L.P1 = b.take<u32>(L.nC1);
   L.blocksum = b.take<u32>(L.nC1 / (SCAN_BLOCK * SCAN_ITEMS) + 2);
-  L.total = b.take<u32>(4);
   L.digits = b.take<uint16_t>(L.cap);
   L.coarse = b.take<u32>(L.cap);
   L.bigbins = b.take<BigBins>(1);
   L.big_items_max = L.cap / SORTBIG_CHUNK + SORTBIG_MAXBINS + 1;
   L.bigT = b.take<u32>(L.big_items_max * 256);
-  L.sidx = b.take<u32>(L.cap);
-  L.sbid = b.take<u32>(L.cap + 1);
-  L.buckets = b.take<u32>(L.NB * IO::REC_WORDS);
+  b.take<u32>(64);
+  Bump c(accum_ws, ~(size_t)0);
+  L.buckets = c.take<u32>(L.NB * IO::REC_WORDS);
   const size_t T1 = (L.cap + p.L1 - 1) / p.L1;
   L.slots0 = 2 * T1;
   const size_t T2 = (L.slots0 + p.LK - 1) / p.LK;
   L.slots1 = 2 * T2;
-  L.slot_bid[0] = b.take<u32>(L.slots0);
-  L.slot_pts[0] = b.take<u32>(L.slots0 * IO::REC_WORDS);
-  L.slot_bid2 = b.take<u32>(L.slots0);
-  L.slot_bid[1] = b.take<u32>(L.slots1);
-  L.slot_pts[1] = b.take<u32>(L.slots1 * IO::REC_WORDS);
+  L.slot_bid[0] = c.take<u32>(L.slots0);
+  L.slot_pts[0] = c.take<u32>(L.slots0 * IO::REC_WORDS);
+  L.slot_bid2 = c.take<u32>(L.slots0);
+  L.slot_bid[1] = c.take<u32>(L.slots1);
+  L.slot_pts[1] = c.take<u32>(L.slots1 * IO::REC_WORDS);
+  c.take<u32>(64);
   L.m1 = (((size_t)1 << p.c) + p.S - 1) / p.S;
-  b.take<u32>(64);
-  L.bytes = b.off;
+  if (rb) {
+    rb->sorted = (a.off + 255) & ~(size_t)255;
+    rb->sort_ws = (b.off + 255) & ~(size_t)255;
+    rb->accum_ws = (c.off + 255) & ~(size_t)255;
+  }
+  L.bytes = a.off + b.off + c.off;
   return L;
+}
+template <class CV>
+static RegionBytes region_bytes(int n) {
+  RegionBytes rb;
+  make_layout3<CV>(make_plan(n), nullptr, nullptr, nullptr, &rb);
+  return rb;
 }
 
 // The "tail" buffers (window-sum elements): the only state the latency-bound tail phase reads.
@@ -124,22 +147,20 @@ static size_t tail_layout(const MsmPlan& p, MsmLayout& L, void* tail, size_t tai
   return b.off;
 }
 
-// Head phase: everything that is throughput-bound (conversion, sort, bucket accumulation, run
-// merge, the first window-sum level).  Leaves W * 2^c / S window-sum elements in the tail buffers.
+// SORT stage: bases -> affine Montgomery, digits, two-level counting sort.  Memory / LDS-bound;
+// leaves the "sorted set".
 template <class CV>
-static int var_msm_head(const void* d_bases, const void* d_scalars, int n, void* ws, size_t ws_bytes, void* tail,
-                        size_t tail_bytes, hipStream_t st) {
-  using CT = CV;  // (an out-of-line-multiplication variant for the tails measured 40 % slower)
+static int var_msm_sort(const void* d_bases, const void* d_scalars, int n, void* sorted, size_t sorted_bytes,
+                        void* sort_ws, size_t sort_ws_bytes, hipStream_t st) {
   const MsmPlan p = make_plan(n);
-  MsmLayout L = make_layout<CV>(p, ws, ws_bytes);
-  if (L.bytes > ws_bytes)
-    return fail(OZK_E_INVALID, "workspace too small: need %zu bytes, got %zu", L.bytes, ws_bytes);
-  const size_t tneed = tail_layout<CV>(p, L, tail, tail_bytes);
-  if (tneed > tail_bytes) return fail(OZK_E_INVALID, "tail buffer too small: need %zu bytes, got %zu", tneed, tail_bytes);
+  RegionBytes rb;
+  const MsmLayout L = make_layout3<CV>(p, sorted, sort_ws, nullptr, &rb);
+  if (rb.sorted > sorted_bytes || rb.sort_ws > sort_ws_bytes)
+    return fail(OZK_E_INVALID, "sort buffers too small: need %zu + %zu bytes, got %zu + %zu", rb.sorted, rb.sort_ws,
+                sorted_bytes, sort_ws_bytes);
   const int TB = 256;
   const u32* bases = (const u32*)d_bases;
   const u32* scalars = (const u32*)d_scalars;
-
   OZK_HIP(hipMemsetAsync(L.total, 0, 4 * sizeof(u32), st));
   hipLaunchKernelGGL((k_convert_bases<CV>), dim3((n + TB - 1) / TB), dim3(TB), 0, st, bases, L.aff, n);
   hipLaunchKernelGGL(k_digits, dim3((n + TB - 1) / TB), dim3(TB), 0, st, scalars, n, p.c, p.W, L.digits);
@@ -159,13 +180,32 @@ static int var_msm_head(const void* d_bases, const void* d_scalars, int n, void*
   const u32 big_thresh = (u32)(n / 64) > SORT_BIG ? (u32)(n / 64) : SORT_BIG;
   hipLaunchKernelGGL(k_sort2, dim3(nbins), dim3(SORT_BLOCK), 0, st, L.coarse, L.P1, L.total, p.c, L.lo_bits, L.NH,
                      L.nblk, nbins, big_thresh, L.hist, L.sidx, L.sbid);
-  // bins above SORT_BIG entries (skewed digits), split over a fixed grid; no-ops otherwise
+  // bins above the threshold (skewed digits), split over a fixed grid; no-ops otherwise
   hipLaunchKernelGGL(k_sortbig_list, dim3(1), dim3(256), 0, st, L.P1, L.total, L.nblk, nbins, big_thresh, L.bigbins);
   hipLaunchKernelGGL(k_sortbig_count, dim3(1024), dim3(SORT_BLOCK), 0, st, L.coarse, L.bigbins, L.bigT);
   hipLaunchKernelGGL(k_sortbig_scan, dim3(SORTBIG_MAXBINS), dim3(256), 0, st, L.bigbins, L.bigT, p.c, L.lo_bits, L.NH,
                      L.hist);
   hipLaunchKernelGGL(k_sortbig_scatter, dim3(1024), dim3(SORT_BLOCK), 0, st, L.coarse, L.bigbins, L.bigT, p.c,
                      L.lo_bits, L.NH, L.sidx, L.sbid);
+  OZK_HIP(hipGetLastError());
+  return OZK_OK;
+}
+
+// ACCUMULATE stage: bucket accumulation, run merge, generic levels, first window-sum level.
+// Vector-ALU-bound.  Reads the sorted set, leaves W * 2^c / S window-sum elements in the tail buffers.
+template <class CV>
+static int var_msm_accum(int n, void* sorted, size_t sorted_bytes, void* accum_ws, size_t accum_ws_bytes, void* tail,
+                         size_t tail_bytes, hipStream_t st) {
+  using CT = CV;  // (an out-of-line-multiplication variant for the tails measured 40 % slower)
+  const MsmPlan p = make_plan(n);
+  RegionBytes rb;
+  MsmLayout L = make_layout3<CV>(p, sorted, nullptr, accum_ws, &rb);
+  if (rb.sorted > sorted_bytes || rb.accum_ws > accum_ws_bytes)
+    return fail(OZK_E_INVALID, "accumulate buffers too small: need %zu + %zu bytes, got %zu + %zu", rb.sorted,
+                rb.accum_ws, sorted_bytes, accum_ws_bytes);
+  const size_t tneed = tail_layout<CV>(p, L, tail, tail_bytes);
+  if (tneed > tail_bytes) return fail(OZK_E_INVALID, "tail buffer too small: need %zu bytes, got %zu", tneed, tail_bytes);
+  const int TB = 256;
   // level 1 over the sorted entries
   size_t lanes = (L.cap + p.L1 - 1) / p.L1;
   const bool prof = g_prof.on && g_prof.created && g_prof.count < ProfState::MAXP;
@@ -200,6 +240,20 @@ static int var_msm_head(const void* d_bases, const void* d_scalars, int n, void*
                      L.buckets, L.hist, m_in, p.S, 0, L.wA[0], L.wR[0], m_out, p.W);
   OZK_HIP(hipGetLastError());
   return OZK_OK;
+}
+
+// Head = SORT + ACCUMULATE on one stream, the three regions carved from one workspace.
+template <class CV>
+static int var_msm_head(const void* d_bases, const void* d_scalars, int n, void* ws, size_t ws_bytes, void* tail,
+                        size_t tail_bytes, hipStream_t st) {
+  const RegionBytes rb = region_bytes<CV>(n);
+  if (rb.sorted + rb.sort_ws + rb.accum_ws > ws_bytes)
+    return fail(OZK_E_INVALID, "workspace too small: need %zu bytes, got %zu", rb.sorted + rb.sort_ws + rb.accum_ws,
+                ws_bytes);
+  uint8_t* w = (uint8_t*)ws;
+  int rc = var_msm_sort<CV>(d_bases, d_scalars, n, w, rb.sorted, w + rb.sorted, rb.sort_ws, st);
+  if (rc) return rc;
+  return var_msm_accum<CV>(n, w, rb.sorted, w + rb.sorted + rb.sort_ws, rb.accum_ws, tail, tail_bytes, st);
 }
 
 // Tail phase: the latency-bound remainder (wave-cooperative window-sum levels, Horner over the
@@ -255,7 +309,8 @@ static size_t var_msm_tail_bytes(int n) {
 template <class CV>
 static int var_msm_dev(const void* d_bases, const void* d_scalars, int n, void* d_out, void* ws,
                        size_t ws_bytes, hipStream_t st) {
-  const size_t main_bytes = make_layout<CV>(make_plan(n), nullptr, 0).bytes;
+  const RegionBytes rb0 = region_bytes<CV>(n);
+  const size_t main_bytes = rb0.sorted + rb0.sort_ws + rb0.accum_ws;
   const size_t tb = var_msm_tail_bytes<CV>(n);
   if (main_bytes + tb > ws_bytes)
     return fail(OZK_E_INVALID, "workspace too small: need %zu bytes, got %zu", main_bytes + tb, ws_bytes);
@@ -266,12 +321,13 @@ static int var_msm_dev(const void* d_bases, const void* d_scalars, int n, void* 
 }
 
 template <class CV>
-static size_t var_msm_ws_bytes(int n) {
-  return make_layout<CV>(make_plan(n), nullptr, 0).bytes + var_msm_tail_bytes<CV>(n);
+static size_t var_msm_head_ws_bytes(int n) {
+  const RegionBytes rb = region_bytes<CV>(n);
+  return rb.sorted + rb.sort_ws + rb.accum_ws;
 }
 template <class CV>
-static size_t var_msm_head_ws_bytes(int n) {
-  return make_layout<CV>(make_plan(n), nullptr, 0).bytes;
+static size_t var_msm_ws_bytes(int n) {
+  return var_msm_head_ws_bytes<CV>(n) + var_msm_tail_bytes<CV>(n);
 }
 
 // host-buffer variant: H2D, run, D2H.  Buffers are per call (re-entrant; callers are
@@ -358,6 +414,36 @@ int ozk_var_msm_head_dev(const void* d_bases, const void* d_scalars, int32_t n, 
                                (hipStream_t)stream);
   return var_msm_head<G2Cfg>(d_bases, d_scalars, n, d_workspace, workspace_bytes, d_tail, tail_bytes,
                              (hipStream_t)stream);
+}
+int ozk_var_msm_stage_bytes(int32_t n, int32_t type, size_t* sorted_bytes, size_t* sort_ws_bytes,
+                            size_t* accum_ws_bytes) {
+  if (n <= 0 || n > (1 << 24) || !sorted_bytes || !sort_ws_bytes || !accum_ws_bytes)
+    return fail(OZK_E_INVALID, "bad argument");
+  const RegionBytes rb = type == OZK_G1 ? region_bytes<G1Cfg>(n) : region_bytes<G2Cfg>(n);
+  *sorted_bytes = rb.sorted;
+  *sort_ws_bytes = rb.sort_ws;
+  *accum_ws_bytes = rb.accum_ws;
+  return OZK_OK;
+}
+int ozk_var_msm_sort_dev(const void* d_bases, const void* d_scalars, int32_t n, int32_t type, void* d_sorted,
+                         size_t sorted_bytes, void* d_sort_ws, size_t sort_ws_bytes, void* stream) {
+  if (!d_bases || !d_scalars || !d_sorted || !d_sort_ws) return fail(OZK_E_INVALID, "null pointer argument");
+  if (n <= 0 || n > (1 << 24)) return fail(OZK_E_INVALID, "batch_size %d out of range [1, 2^24]", n);
+  if (type == OZK_G1)
+    return var_msm_sort<G1Cfg>(d_bases, d_scalars, n, d_sorted, sorted_bytes, d_sort_ws, sort_ws_bytes,
+                               (hipStream_t)stream);
+  return var_msm_sort<G2Cfg>(d_bases, d_scalars, n, d_sorted, sorted_bytes, d_sort_ws, sort_ws_bytes,
+                             (hipStream_t)stream);
+}
+int ozk_var_msm_accum_dev(int32_t n, int32_t type, void* d_sorted, size_t sorted_bytes, void* d_accum_ws,
+                          size_t accum_ws_bytes, void* d_tail, size_t tail_bytes, void* stream) {
+  if (!d_sorted || !d_accum_ws || !d_tail) return fail(OZK_E_INVALID, "null pointer argument");
+  if (n <= 0 || n > (1 << 24)) return fail(OZK_E_INVALID, "batch_size %d out of range [1, 2^24]", n);
+  if (type == OZK_G1)
+    return var_msm_accum<G1Cfg>(n, d_sorted, sorted_bytes, d_accum_ws, accum_ws_bytes, d_tail, tail_bytes,
+                                (hipStream_t)stream);
+  return var_msm_accum<G2Cfg>(n, d_sorted, sorted_bytes, d_accum_ws, accum_ws_bytes, d_tail, tail_bytes,
+                              (hipStream_t)stream);
 }
 int ozk_var_msm_tail_dev(int32_t n, int32_t type, void* d_tail, size_t tail_bytes, void* d_out, void* stream) {
   if (!d_tail || !d_out) return fail(OZK_E_INVALID, "null pointer argument");

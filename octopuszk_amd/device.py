@@ -14,7 +14,11 @@ def _stream():
 
 
 class VarMsmWorkspace:
-    """Pre-allocated workspace + output for repeated device-resident MSMs of size n."""
+    """Pre-allocated workspace + output for repeated device-resident MSMs of size n.
+
+    The library receives raw device pointers, so — as with any stream-ordered foreign library —
+    this object (its workspace) and the input tensors must stay alive until the stream the work
+    was enqueued on has been synchronised; `run` keeps references to its last inputs to help."""
 
     def __init__(self, n, type_=1, device="cuda"):
         L = _lib.load()
@@ -29,6 +33,7 @@ class VarMsmWorkspace:
         """d_bases: uint8 [n*96|192], d_scalars: uint8 [n*32] — wire format, in HBM.
         Asynchronous on the current stream; returns the output tensor (192|384 B)."""
         L = _lib.load()
+        self._inputs = (d_bases, d_scalars)
         _lib.check(L.ozk_var_msm_dev(_ptr(d_bases), _ptr(d_scalars), self.n, self.type, _ptr(self.out),
                                      _ptr(self.ws), self.bytes, _stream()))
         return self.out

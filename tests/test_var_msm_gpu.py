@@ -236,6 +236,8 @@ def test_g1_profiler_shaped_full_size():
     sc = np.frombuffer(b"".join(v.to_bytes(32, "little") for v in vals), dtype=np.uint8).copy()
     base = o.G1.to_affine(o.G1.mul(o.G1.one, 987654321))
     bases = np.frombuffer(o.g1_to_wire(base) * n, dtype=np.uint8).copy()
-    out = dev.VarMsmWorkspace(n, 1).run(torch.from_numpy(bases).cuda(), torch.from_numpy(sc).cuda())
+    d_bases, d_scalars = torch.from_numpy(bases).cuda(), torch.from_numpy(sc).cuda()
+    ws = dev.VarMsmWorkspace(n, 1)
+    out = ws.run(d_bases, d_scalars)
     torch.cuda.synchronize()
     assert bytes(out.cpu().numpy()) == o.g1_out_le(o.G1.to_affine(o.G1.mul(base, sum(vals) % o.R)))
