@@ -775,14 +775,17 @@ __device__ void write_normalised(const Jac<CV>& r, u32* out) {
 // The Horner chain runs on ONE lane for ~1.5 ms.  When another MSM's bucket accumulation shares
 // its SIMD, either the chain starves (no priority) or — with s_setprio — the co-resident
 // accumulation waves crawl and that whole kernel waits for them (measured: 1.38 -> 1.65 ms).
-// So the kernel takes a compute unit for itself: four waves, one per SIMD, each declaring all
-// 512 VGPRs; wave 0 works, the other three sleep until it is done.  The accumulation kernel
-// loses 1 CU of 256 instead of 20 % of its time.
-template <class CV>
+// EXCLUSIVE = true lets the kernel take a compute unit for itself: four waves, one per SIMD, each
+// declaring all 512 VGPRs; wave 0 works, the other three sleep until it is done.  The accumulation
+// kernel then loses 1 CU of 256 instead of 20 % of its time — experimental, see msm_var.hip.
+template <class CV, bool EXCLUSIVE>
 __global__ void __launch_bounds__(256) k_finalize(const u32* __restrict__ A_w, int W, int c, u32* __restrict__ out) {
   using IO = CurveIO<CV>;
   __shared__ volatile int done;
-  asm volatile("v_mov_b32 v255, 0\n\tv_accvgpr_write_b32 a255, 0" ::: "v255", "a255");  // 256 VGPRs + 256 AGPRs = the SIMD's whole register file
+  if constexpr (EXCLUSIVE) {
+    // 256 VGPRs + 256 AGPRs = the SIMD's whole register file
+    asm volatile("v_mov_b32 v255, 0\n\tv_accvgpr_write_b32 a255, 0" ::: "v255", "a255");
+  }
   if (blockIdx.x != 0) return;
   if (threadIdx.x == 0) done = 0;
   __syncthreads();

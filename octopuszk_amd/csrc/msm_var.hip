@@ -292,7 +292,15 @@ static int var_msm_tail(int n, void* tail, size_t tail_bytes, void* d_out, hipSt
     g += 6;
     k ^= 1;
   }
-  hipLaunchKernelGGL((k_finalize<CT>), dim3(1), dim3(256), 0, st, L.wA[k], p.W, p.c, (u32*)d_out);
+  // EXPERIMENTAL (off): with OZK_FINALIZE_EXCLUSIVE=1 the Horner kernel declares the whole register
+  // file of a CU so that no bucket-accumulation wave shares its SIMDs: +9 % pipelined throughput
+  // (362 -> 395 Mscalar-mul/s), but the process aborted reproducibly when ~60 HIP streams had been
+  // created and destroyed before it (suspected: mid-wave preemption of 512-register waves under
+  // queue oversubscription), so it is not the default.
+  if (env_int("OZK_FINALIZE_EXCLUSIVE", 0))
+    hipLaunchKernelGGL((k_finalize<CT, true>), dim3(1), dim3(256), 0, st, L.wA[k], p.W, p.c, (u32*)d_out);
+  else
+    hipLaunchKernelGGL((k_finalize<CT, false>), dim3(1), dim3(256), 0, st, L.wA[k], p.W, p.c, (u32*)d_out);
   OZK_HIP(hipGetLastError());
   return OZK_OK;
 }
