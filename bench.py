@@ -162,7 +162,13 @@ def main():
                     "kernel": "k_segreduce<G1Cfg,true> (level-1 bucket accumulation)",
                     "kernel_avg_ms": round(k_ms, 4), "launches_timed": launches.value,
                     "algorithmic_bytes_per_launch": alg_bytes,
-                    "note": "integer-ALU-bound: 11 Fq mulmod per mixed add x %d windows; see DESIGN.md" % wn.value}
+                    # the bound that actually holds: v_mad_u64_u32 issue.  10 Montgomery
+                    # multiplications per XYZZ mixed addition x n x windows, against the 172 G mulmod/s
+                    # this chip sustains on back-to-back multiplications (profiles/r01_ubench.txt)
+                    "alu": {"achieved": round(10.0 * n * wn.value / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else 0.0,
+                            "peak": 172.0, "unit": "G mulmod/s",
+                            "frac": round(10.0 * n * wn.value / (k_ms * 1e-3) / 1e9 / 172.0, 3) if k_ms > 0 else 0.0},
+                    "note": "integer-ALU-bound: 10 Fq mulmod per XYZZ mixed add x %d windows; see DESIGN.md" % wn.value}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             from oracle import coracle  # checker / baseline only
