@@ -109,6 +109,9 @@ int ozk_points_sum_dev(const void* d_points, int32_t k, int32_t type, void* d_ou
 int ozk_prof_enable(int on);
 int ozk_prof_dominant_kernel_ms(double* avg_ms, int* launches);
 int ozk_var_msm_plan(int32_t n, int32_t* window_bits, int32_t* windows);
+/* 1 when the MSM of n pairs runs as 2n half-length pairs through the GLV endomorphism (the windows
+ * reported above then cover 128 bits); 0 otherwise (n > 2^23 or OZK_MSM_GLV=0). */
+int ozk_var_msm_glv(int32_t n);
 
 /* Synthetic inputs for benchmarks / full-size tests (BASELINE.md config 2 generator):
  * writes n G1 bases P_i = k_i * G, k_i = splitmix64(seed + i) (k_i = 1 if that is 0), in the

@@ -113,6 +113,10 @@ OZK_HD auto mul(const Fe<P, B1>& a, const Fe<P, B2>& b) {
   return r;
 }
 
+// multiplication by a base-field constant; overloaded component-wise for Fq2 (fq2.cuh)
+template <class P, int B1>
+OZK_HD auto scale(const Fe<P, B1>& a, const Fe<P, 16>& k) { return mul(a, k); }
+
 template <class P, int B1>
 OZK_HD auto sqr(const Fe<P, B1>& a) {
   static_assert((long long)B1 * B1 <= (long long)MONT_SLACK * 256, "Montgomery input bounds too large");

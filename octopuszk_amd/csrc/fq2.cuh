@@ -107,6 +107,13 @@ OZK_HD Fe2<32> mul(const Fe2<B1>& a_in, const Fe2<B2>& b_in) {
     return r;
   }
 }
+template <int B1>
+OZK_HD Fe2<32> scale(const Fe2<B1>& a, const Fe<FqParams, 16>& k) {
+  Fe2<32> r;
+  r.c0 = Fe<FqParams, 32>(mul(a.c0, k));
+  r.c1 = Fe<FqParams, 32>(mul(a.c1, k));
+  return r;
+}
 // (a0 + a1 u)^2 = (a0+a1)(a0-a1) + 2 a0 a1 u        (Fp2.java:94-103 with nonresidue = -1)
 template <int B1>
 OZK_HD Fe2<32> sqr(const Fe2<B1>& a_in) {

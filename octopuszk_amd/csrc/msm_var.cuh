@@ -24,15 +24,18 @@
 //   finalize  Horner over the windows, affine normalisation, wire-out bytes
 #pragma once
 #include "curve.cuh"
+#include "glv.cuh"
 
 namespace ozk {
 
 constexpr u32 BID_NONE = 0xffffffffu;
 
 struct MsmPlan {
-  int n;        // points
+  int n_in;     // (scalar, base) pairs handed in
+  int glv;      // 1: every pair is split into two half-length pairs by the GLV endomorphism (glv.cuh)
+  int n;        // points the pipeline sorts and accumulates: n_in, or 2 * n_in with GLV
   int c;        // window bits (<= 16)
-  int W;        // windows = ceil(256 / c)
+  int W;        // windows = ceil(256 / c), or ceil(128 / c) with GLV
   int L1;       // sorted entries per lane at level 1
   int LK;       // slots per lane at levels >= 2
   int S;        // buckets per lane per wsum level (power of two)
@@ -53,9 +56,19 @@ OZK_HD u32 scalar_digit(const u32 (&s)[8], int w, int c) {
 // are affine) costs 2 Montgomery conversions; Z == 0 -> infinity marker; any other Z is
 // normalised with a per-lane Fermat inversion (correct for reference-produced
 // Jacobian keys, slower).
+// beta of the GLV endomorphism for this curve's base field (G2: beta^2, acting on both Fq2 components)
+template <class CV>
+OZK_HD Fe<FqParams, 16> glv_beta() {
+  if constexpr (CurveIO<CV>::CW == 16) return fe_const<FqParams, 16>(GlvConsts::BETA_G2);
+  else return fe_const<FqParams, 16>(GlvConsts::BETA_G1);
+}
+
+// With GLV (neg != nullptr; k_digits has run): record i = (x, +-y), record n + i = (beta x, +-y), the
+// signs being those of the two half scalars, so that nothing downstream knows about signs.
 template <class CV>
 __global__ void __launch_bounds__(256) k_convert_bases(const u32* __restrict__ wire,
-                                                       u32* __restrict__ aff, int n) {
+                                                       u32* __restrict__ aff, int n,
+                                                       const uint8_t* __restrict__ neg_flags) {
   using IO = CurveIO<CV>;
   using EA = typename CV::EA;
   using ET = ElemTraits<EA>;
@@ -85,7 +98,18 @@ __global__ void __launch_bounds__(256) k_convert_bases(const u32* __restrict__ w
   // canonical (< p) so that equal points have equal records
   q.x = EA(canonical(q.x));
   q.y = EA(canonical(q.y));
+  if (neg_flags == nullptr) {
+    IO::store_aff(q, o);
+    return;
+  }
+  Aff<EA> q2;
+  q2.x = EA(canonical(scale(q.x, glv_beta<CV>())));
+  q2.y = q.y;
+  const EA ny = EA(canonical(neg(q.y)));   // infinity marker (0, 0) stays (0, 0)
+  if (neg_flags[i]) q.y = ny;
+  if (neg_flags[n + i]) q2.y = ny;
   IO::store_aff(q, o);
+  IO::store_aff(q2, aff + (size_t)(n + i) * IO::AFF_WORDS);
 }
 
 // ------------------------------------------------------------------ digits
@@ -100,6 +124,32 @@ __global__ void __launch_bounds__(256) k_digits(const u32* __restrict__ scalars,
   s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w;
   s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
   for (int w = 0; w < W; w++) digits[(size_t)w * n + i] = (uint16_t)scalar_digit(s, w, c);
+}
+
+// GLV form: scalar i (reduced mod r) -> |k1|, |k2| < 2^127 (glv.cuh); virtual scalar i = |k1| and
+// n + i = |k2| of a 2n-point MSM with W = ceil(128 / c) windows; the signs go to neg_flags for
+// k_convert_bases.
+__global__ void __launch_bounds__(256) k_digits_glv(const u32* __restrict__ scalars, int n, int c, int W,
+                                                    uint16_t* __restrict__ digits, uint8_t* __restrict__ neg_flags) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 s[8];
+  const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
+  const uint4 a = sp[0], b = sp[1];
+  s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w;
+  s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+  u32 k1[4], k2[4];
+  bool n1, n2;
+  glv_decompose(s, k1, n1, k2, n2);
+  u32 e1[8] = {k1[0], k1[1], k1[2], k1[3], 0, 0, 0, 0};
+  u32 e2[8] = {k2[0], k2[1], k2[2], k2[3], 0, 0, 0, 0};
+  const size_t ne = 2 * (size_t)n;
+  for (int w = 0; w < W; w++) {
+    digits[(size_t)w * ne + i] = (uint16_t)scalar_digit(e1, w, c);
+    digits[(size_t)w * ne + n + i] = (uint16_t)scalar_digit(e2, w, c);
+  }
+  neg_flags[i] = n1;
+  neg_flags[n + i] = n2;
 }
 
 // ------------------------------------------------------------------ two-level counting sort

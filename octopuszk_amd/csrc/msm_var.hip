@@ -26,17 +26,22 @@ struct ProfState {
 };
 static ProfState g_prof;
 
+// GLV needs 2n <= 2^24 sortable points (24-bit index in the packed coarse words).
+constexpr int GLV_MAX_N = 1 << 23;
+
 static MsmPlan make_plan(int n) {
   MsmPlan p;
-  p.n = n;
-  int c = ilog2((uint32_t)n) - 4;
+  p.n_in = n;
+  p.glv = env_int("OZK_MSM_GLV", 1) != 0 && n <= GLV_MAX_N;
+  p.n = p.glv ? 2 * n : n;
+  int c = ilog2((uint32_t)p.n) - 4;
   if (c < 4) c = 4;
   if (c > 16) c = 16;
   c = env_int("OZK_MSM_C", c);
   if (c < 1) c = 1;
   if (c > 16) c = 16;
   p.c = c;
-  p.W = (256 + c - 1) / c;
+  p.W = ((p.glv ? 128 : 256) + c - 1) / c;
   p.L1 = env_int("OZK_MSM_L1", 32);
   p.LK = env_int("OZK_MSM_LK", 16);
   if (p.L1 < 2) p.L1 = 2;
@@ -52,6 +57,7 @@ struct MsmLayout {
   u32* aff;
   u32 *hist, *C1, *P1, *blocksum, *total;  // total[0] = sorted entries, total[1] = live partial slots
   uint16_t* digits;
+  uint8_t* neg_flags;  // GLV: sign of each half scalar
   u32 *coarse, *sidx, *sbid;
   BigBins* bigbins;
   u32* bigT;
@@ -98,6 +104,7 @@ static MsmLayout make_layout3(const MsmPlan& p, void* sorted, void* sort_ws, voi
   L.P1 = b.take<u32>(L.nC1);
   L.blocksum = b.take<u32>(L.nC1 / (SCAN_BLOCK * SCAN_ITEMS) + 2);
   L.digits = b.take<uint16_t>(L.cap);
+  L.neg_flags = b.take<uint8_t>((size_t)p.n);
   L.coarse = b.take<u32>(L.cap);
   L.bigbins = b.take<BigBins>(1);
   L.big_items_max = L.cap / SORTBIG_CHUNK + SORTBIG_MAXBINS + 1;
@@ -161,9 +168,19 @@ static int var_msm_sort(const void* d_bases, const void* d_scalars, int n, void*
   const int TB = 256;
   const u32* bases = (const u32*)d_bases;
   const u32* scalars = (const u32*)d_scalars;
+  const int n_in = p.n_in;
+  n = p.n;  // from here on: the points the pipeline sorts (2 * n_in with GLV)
   OZK_HIP(hipMemsetAsync(L.total, 0, 4 * sizeof(u32), st));
-  hipLaunchKernelGGL((k_convert_bases<CV>), dim3((n + TB - 1) / TB), dim3(TB), 0, st, bases, L.aff, n);
-  hipLaunchKernelGGL(k_digits, dim3((n + TB - 1) / TB), dim3(TB), 0, st, scalars, n, p.c, p.W, L.digits);
+  if (p.glv) {
+    hipLaunchKernelGGL(k_digits_glv, dim3((n_in + TB - 1) / TB), dim3(TB), 0, st, scalars, n_in, p.c, p.W, L.digits,
+                       L.neg_flags);
+    hipLaunchKernelGGL((k_convert_bases<CV>), dim3((n_in + TB - 1) / TB), dim3(TB), 0, st, bases, L.aff, n_in,
+                       (const uint8_t*)L.neg_flags);
+  } else {
+    hipLaunchKernelGGL((k_convert_bases<CV>), dim3((n_in + TB - 1) / TB), dim3(TB), 0, st, bases, L.aff, n_in,
+                       (const uint8_t*)nullptr);
+    hipLaunchKernelGGL(k_digits, dim3((n_in + TB - 1) / TB), dim3(TB), 0, st, scalars, n_in, p.c, p.W, L.digits);
+  }
   // two-level counting sort by (window, digit): per-block LDS counts of the hi part, one global
   // exclusive scan, coarse scatter, then one block per coarse bin finishes by the lo part
   const size_t lds1 = (size_t)L.NH * sizeof(u32);
@@ -550,6 +567,8 @@ int ozk_var_msm_plan(int32_t n, int32_t* window_bits, int32_t* windows) {
   *windows = p.W;
   return OZK_OK;
 }
+
+int ozk_var_msm_glv(int32_t n) { return n > 0 ? make_plan(n).glv : 0; }
 
 const char* ozk_last_error(void) { return err_buf(); }
 int ozk_version(void) { return 1; }

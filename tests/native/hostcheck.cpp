@@ -116,3 +116,25 @@ extern "C" void hc_g2_op(int op, const u32* pw, const u32* qw, int k, u32* out) 
   ElemTraits<J2::EY>::to_wire(r.Y, out + 16);
   ElemTraits<J2::EZ>::to_wire(r.Z, out + 32);
 }
+
+// ---- GLV decomposition (glv.cuh) ----
+#include "../../octopuszk_amd/csrc/glv.cuh"
+// out[0..4) = |k1|, out[4..8) = |k2|, out[8] = neg1, out[9] = neg2
+extern "C" void hc_glv(const u32* k, u32* out) {
+  u32 kk[8], k1[4], k2[4];
+  bool n1, n2;
+  memcpy(kk, k, 32);
+  glv_decompose(kk, k1, n1, k2, n2);
+  memcpy(out, k1, 16);
+  memcpy(out + 4, k2, 16);
+  out[8] = n1;
+  out[9] = n2;
+}
+// beta constants out of Montgomery form: out[0..8) = beta_G1, out[8..16) = beta_G2
+extern "C" void hc_glv_beta(u32* out) {
+  u32 w[8];
+  from_mont(fe_const<FqParams, 16>(GlvConsts::BETA_G1), w);
+  memcpy(out, w, 32);
+  from_mont(fe_const<FqParams, 16>(GlvConsts::BETA_G2), w);
+  memcpy(out + 8, w, 32);
+}

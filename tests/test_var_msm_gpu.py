@@ -241,3 +241,61 @@ def test_g1_profiler_shaped_full_size():
     out = ws.run(d_bases, d_scalars)
     torch.cuda.synchronize()
     assert bytes(out.cpu().numpy()) == o.g1_out_le(o.G1.to_affine(o.G1.mul(base, sum(vals) % o.R)))
+
+
+# ---- GLV endomorphism path (csrc/glv.cuh): scalars that stress the decomposition ----
+_LAM = 4407920970296243842393367215006156084916469457145843978461
+_GLV_EDGE = [0, 1, 2, o.R - 1, o.R - 2, _LAM, _LAM - 1, _LAM + 1, o.R - _LAM, o.R - _LAM - 1,
+             (1 << 127) - 1, 1 << 127, (1 << 127) + 1, 1 << 128, 1 << 253, o.R // 2, o.R // 3,
+             9931322734385697763, 147946756881789319010696353538189108491,
+             # not reduced: the library reduces any 256-bit value mod r
+             o.R, o.R + 1, (1 << 256) - 1, 5 * o.R + 7]
+
+
+def _le32_any(s):
+    return int(s).to_bytes(32, "little")
+
+
+def test_g1_glv_edge_scalars():
+    from octopuszk_amd import variable_base_msm as vb
+    G = o.G1
+    rng = random.Random(31)
+    scalars = _GLV_EDGE + [rng.randrange(1 << 256) for _ in range(41)]
+    bases = _rand_points(G, len(scalars), rng)
+    bases[5] = G.zero
+    raw = vb.variable_base_serial_msm_native_helper(vb.marshal_g1(bases), b"".join(map(_le32_any, scalars)),
+                                                    len(scalars), 1, 0)
+    want = G.to_affine(o.naive_msm(G, [s % o.R for s in scalars], bases))
+    assert raw == o.g1_out_le(want)
+    # each edge scalar on its own (a one-pair MSM is the scalar multiplication itself)
+    for s in _GLV_EDGE:
+        raw = vb.variable_base_serial_msm_native_helper(vb.marshal_g1(bases[:1]), _le32_any(s), 1, 1, 0)
+        assert raw == o.g1_out_le(G.to_affine(G.mul(bases[0], s % o.R))), hex(s)
+
+
+def test_g2_glv_edge_scalars():
+    from octopuszk_amd import variable_base_msm as vb
+    G = o.G2
+    rng = random.Random(32)
+    scalars = _GLV_EDGE + [rng.randrange(1 << 256) for _ in range(9)]
+    bases = _rand_points(G, len(scalars), rng)
+    raw = vb.variable_base_serial_msm_native_helper(vb.marshal_g2(bases), b"".join(map(_le32_any, scalars)),
+                                                    len(scalars), 2, 0)
+    want = G.to_affine(o.naive_msm(G, [s % o.R for s in scalars], bases))
+    assert raw == o.g2_out_le(want)
+
+
+@pytest.mark.parametrize("type_", [1, 2])
+def test_glv_off_equals_glv_on(type_, monkeypatch):
+    # OZK_MSM_GLV=0 runs the plain 256-bit windows; both must give the same bytes
+    G = o.G1 if type_ == 1 else o.G2
+    rng = random.Random(33 + type_)
+    n = 700 if type_ == 1 else 150
+    bases = _rand_points(G, 16, rng) * (n // 16 + 1)
+    bases = bases[:n]
+    scalars = [rng.randrange(o.R) for _ in range(n)]
+    run = _run_g1 if type_ == 1 else _run_g2
+    on = run(scalars, bases)
+    monkeypatch.setenv("OZK_MSM_GLV", "0")
+    off = run(scalars, bases)
+    assert on == off
