@@ -401,8 +401,10 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sort2(const u32* __restrict__ co
   // Bins of at most S2_TILE entries (every bin of a uniform input: 2^c/2^8 ... n/256 entries) are
   // held in registers between the counting and the scattering sweep: one pipelined read of the
   // bin, no second read.  Larger bins (skewed digits) stream twice.
-  constexpr int S2_PER = 24;
+  // register tile: 2^21 points (GLV at 2^20) put 8192 +- 90 entries into a coarse bin
+  constexpr int S2_PER = 36;
   constexpr u32 S2_TILE = S2_PER * SORT_BLOCK;
+  __shared__ u32 stage[S2_TILE];
   const bool small = (b1 - b0) <= S2_TILE;
   u32 vreg[S2_PER];
   if (small) {
@@ -451,10 +453,14 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sort2(const u32* __restrict__ co
       const bool live = e < b1;
       const u32 lo = vreg[k] & 0xffu;
       const u32 pos = lds_rank(cur, lo, live);
-      if (live) {
-        sidx[pos] = vreg[k] >> 8;
-        sbid[pos] = bucket0 + lo;
-      }
+      if (live) stage[pos - b0] = vreg[k];
+    }
+    __syncthreads();
+    // sorted inside LDS; write out in order (coalesced)
+    for (u32 j = threadIdx.x; j < b1 - b0; j += SORT_BLOCK) {
+      const u32 v = stage[j];
+      sidx[b0 + j] = v >> 8;
+      sbid[b0 + j] = bucket0 + (v & 0xffu);
     }
   } else {
     for (u32 e = b0 + threadIdx.x; e - threadIdx.x < b1; e += SORT_BLOCK) {
@@ -710,9 +716,9 @@ k_runmerge(const u32* __restrict__ bid_in, const u32* __restrict__ pts, int n_sl
 template <class CV, bool FIRSTLEVEL>
 __global__ void __launch_bounds__(256)
 k_wsum(const u32* __restrict__ A_in, const u32* __restrict__ R_in, const u32* __restrict__ hist,
-       int m_in, int S, int g, u32* __restrict__ A_out, u32* __restrict__ R_out, int m_out, int W) {
+       int m_in, int S, int g, u32* __restrict__ A_out, u32* __restrict__ R_out, int m_out, int W, int prio) {
   using IO = CurveIO<CV>;
-  if constexpr (!FIRSTLEVEL) __builtin_amdgcn_s_setprio(3);  // tail phase: see k_wsum_wave
+  if (prio) __builtin_amdgcn_s_setprio(3);  // tail phase: see k_wsum_wave
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= m_out * W) return;
   const int w = t / m_out, j = t - w * m_out;

@@ -64,7 +64,8 @@ struct MsmLayout {
   size_t big_items_max;
   int lo_bits, NH, nblk;
   size_t nC1;
-  u32* buckets;
+  u32* buckets;   // tail region: bucket records, read by the first window-sum level
+  u32* hist_t;    // tail region: copy of the bucket counts (the sorted set is reused by the next head)
   u32 *slot_bid[2], *slot_pts[2], *slot_bid2;
   u32 *wA[2], *wR[2];
   size_t bytes;
@@ -111,7 +112,6 @@ static MsmLayout make_layout3(const MsmPlan& p, void* sorted, void* sort_ws, voi
   L.bigT = b.take<u32>(L.big_items_max * 256);
   b.take<u32>(64);
   Bump c(accum_ws, ~(size_t)0);
-  L.buckets = c.take<u32>(L.NB * IO::REC_WORDS);
   const size_t T1 = (L.cap + p.L1 - 1) / p.L1;
   L.slots0 = 2 * T1;
   const size_t T2 = (L.slots0 + p.LK - 1) / p.LK;
@@ -138,7 +138,8 @@ static RegionBytes region_bytes(int n) {
   return rb;
 }
 
-// The "tail" buffers (window-sum elements): the only state the latency-bound tail phase reads.
+// The "tail" buffers (bucket records + counts, window-sum elements): the only state the
+// latency-bound tail phase reads.
 // They live outside the main workspace so that a caller can keep several MSMs in flight: the
 // head phase of the next MSM may reuse the whole main workspace while this MSM's tail still
 // runs on another stream.
@@ -146,12 +147,33 @@ template <class CV>
 static size_t tail_layout(const MsmPlan& p, MsmLayout& L, void* tail, size_t tail_bytes) {
   using IO = CurveIO<CV>;
   Bump b(tail, tail_bytes);
+  L.NB = (size_t)p.W << p.c;
+  L.m1 = (((size_t)1 << p.c) + p.S - 1) / p.S;
+  L.buckets = b.take<u32>(L.NB * IO::REC_WORDS);
+  L.hist_t = b.take<u32>(L.NB);
   for (int k = 0; k < 2; k++) {
     L.wA[k] = b.take<u32>((size_t)p.W * L.m1 * IO::JAC_WORDS);
     L.wR[k] = b.take<u32>((size_t)p.W * L.m1 * IO::JAC_WORDS);
   }
   b.take<u32>(64);
   return b.off;
+}
+
+// First window-sum level: S buckets per lane, W * 2^c / S lanes.  Only 2 waves per CU at 2^20, so it
+// is latency-bound (32 dependent additions).  It closes the HEAD phase by default.  Measured with
+// two MSMs in flight: opening the TAIL with it instead (OZK_MSM_WSUM0_IN_TAIL=1, where it overlaps
+// the next MSM's bucket accumulation) is SLOWER, 353 vs 395 Mscalar-mul/s — its 512 prioritised
+// waves take a full share of the multiplier issue slots of half the SIMDs and stretch the level-1
+// kernel from 1.36 to 1.50 ms; overlapped work is not free, only its latency is hidden.
+static bool wsum0_in_tail() { return env_int("OZK_MSM_WSUM0_IN_TAIL", 0) != 0; }
+template <class CV>
+static void launch_wsum0(const MsmPlan& p, const MsmLayout& L, hipStream_t st, int prio) {
+  const int TB = 256;
+  const int m_in = 1 << p.c;
+  const int m_out = (m_in + p.S - 1) / p.S;
+  const int tot = m_out * p.W;
+  hipLaunchKernelGGL((k_wsum<CV, true>), dim3((tot + TB - 1) / TB), dim3(TB), 0, st, (const u32*)nullptr,
+                     L.buckets, L.hist_t, m_in, p.S, 0, L.wA[0], L.wR[0], m_out, p.W, prio);
 }
 
 // SORT stage: bases -> affine Montgomery, digits, two-level counting sort.  Memory / LDS-bound;
@@ -249,12 +271,9 @@ static int var_msm_accum(int n, void* sorted, size_t sorted_bytes, void* accum_w
     n_in = 2 * lanes;
     cur ^= 1;
   }
-  // first window-sum level: S buckets per lane, W * 2^c / S lanes (throughput-bound)
-  const int m_in = 1 << p.c;
-  const int m_out = (m_in + p.S - 1) / p.S;
-  const int tot = m_out * p.W;
-  hipLaunchKernelGGL((k_wsum<CT, true>), dim3((tot + TB - 1) / TB), dim3(TB), 0, st, (const u32*)nullptr,
-                     L.buckets, L.hist, m_in, p.S, 0, L.wA[0], L.wR[0], m_out, p.W);
+  // the tail needs the bucket counts after the next head has reused the sorted set
+  OZK_HIP(hipMemcpyAsync(L.hist_t, L.hist, L.NB * sizeof(u32), hipMemcpyDeviceToDevice, st));
+  if (!wsum0_in_tail()) launch_wsum0<CV>(p, L, st, 0);
   OZK_HIP(hipGetLastError());
   return OZK_OK;
 }
@@ -283,6 +302,7 @@ static int var_msm_tail(int n, void* tail, size_t tail_bytes, void* d_out, hipSt
   L.m1 = (((size_t)1 << p.c) + p.S - 1) / p.S;
   const size_t tneed = tail_layout<CV>(p, L, tail, tail_bytes);
   if (tneed > tail_bytes) return fail(OZK_E_INVALID, "tail buffer too small: need %zu bytes, got %zu", tneed, tail_bytes);
+  if (wsum0_in_tail()) launch_wsum0<CV>(p, L, st, env_int("OZK_MSM_WSUM0_PRIO", 1));
   int m_in = (int)L.m1, g = ilog2((uint32_t)p.S), k = 0;
   const int TB = 256;
   const int sg = ilog2((uint32_t)p.S);
@@ -295,7 +315,7 @@ static int var_msm_tail(int n, void* tail, size_t tail_bytes, void* d_out, hipSt
     const int m_out = (m_in + p.S - 1) / p.S;
     const int tot = m_out * p.W;
     hipLaunchKernelGGL((k_wsum<CT, false>), dim3((tot + TB - 1) / TB), dim3(TB), 0, st, L.wA[k], L.wR[k],
-                       (const u32*)nullptr, m_in, p.S, g, L.wA[k ^ 1], L.wR[k ^ 1], m_out, p.W);
+                       (const u32*)nullptr, m_in, p.S, g, L.wA[k ^ 1], L.wR[k ^ 1], m_out, p.W, 1);
     m_in = m_out;
     g += sg;
     k ^= 1;
