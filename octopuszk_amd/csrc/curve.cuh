@@ -132,6 +132,15 @@ struct CurveIO {
     ElemTraits<typename CV::XZZZ>::store_raw(a.ZZZ, p + 3 * RW);
     p[REC_TAG] = TAG_XYZZ;
   }
+  // a record known to carry TAG_XYZZ (the head / tail pieces the level-1 kernel writes)
+  static OZK_HD Xyzz<CV> load_xyzz(const u32* p) {
+    Xyzz<CV> a;
+    a.X = ElemTraits<typename CV::XX>::load_raw(p);
+    a.Y = ElemTraits<typename CV::XY>::load_raw(p + RW);
+    a.ZZ = ElemTraits<typename CV::XZZ>::load_raw(p + 2 * RW);
+    a.ZZZ = ElemTraits<typename CV::XZZZ>::load_raw(p + 3 * RW);
+    return a;
+  }
   static OZK_HD void store_rec_jac(const Jac<CV>& r, u32* p) {
     store_jac(r, p);
     p[REC_TAG] = TAG_JAC;

@@ -207,6 +207,58 @@ OZK_HD Xyzz<CV> xyzz_madd(const Xyzz<CV>& p, const Aff<typename CV::EA>& q) {
   return out;
 }
 
+// dbl-2008-s-1: XYZZ doubling (a = 0).  6M + 4S... used only when a general addition meets P == Q.
+template <class CV>
+OZK_HD Xyzz<CV> xyzz_dbl(const Xyzz<CV>& p) {
+  if (is_inf(p)) return p;
+  const auto U = dbl(p.Y);
+  const auto V = sqr(U);
+  const auto W = mul(U, V);
+  const auto S = mul(p.X, V);
+  const auto xx = sqr(p.X);
+  const auto M = add(dbl(xx), xx);
+  const auto X3 = sub(sqr(M), dbl(S));
+  const auto Y3 = sub(mul(M, sub(S, X3)), mul(W, p.Y));
+  Xyzz<CV> r;
+  r.X = typename CV::XX(X3);
+  r.Y = typename CV::XY(Y3);
+  r.ZZ = typename CV::XZZ(mul(V, p.ZZ));
+  r.ZZZ = typename CV::XZZZ(mul(W, p.ZZZ));
+  return r;
+}
+
+// add-2008-s: XYZZ + XYZZ.  12M + 2S (the Jacobian add-2007-bl is 11M + 5S, plus 2M per XYZZ input
+// converted first), complete: handles infinity on either side, P == Q and P == -Q.
+template <class CV>
+OZK_HD Xyzz<CV> xyzz_add(const Xyzz<CV>& p, const Xyzz<CV>& q) {
+  if (is_inf(q)) return p;
+  if (is_inf(p)) return q;
+  const auto U1 = mul(p.X, q.ZZ);
+  const auto U2 = mul(q.X, p.ZZ);
+  const auto S1 = mul(p.Y, q.ZZZ);
+  const auto S2 = mul(q.Y, p.ZZZ);
+  const auto P = sub(U2, U1);
+  const auto R = sub(S2, S1);
+  if (is_zero(P)) {
+    if (is_zero(R)) return xyzz_dbl(p);
+    Xyzz<CV> z = p;
+    z.ZZ = typename CV::XZZ(el_zero(p.ZZ));
+    z.ZZZ = typename CV::XZZZ(el_zero(p.ZZ));
+    return z;
+  }
+  const auto PP = sqr(P);
+  const auto PPP = mul(P, PP);
+  const auto Q = mul(U1, PP);
+  const auto X3 = sub(sqr(R), add(PPP, dbl(Q)));
+  const auto Y3 = sub(mul(R, sub(Q, X3)), mul(S1, PPP));
+  Xyzz<CV> out;
+  out.X = typename CV::XX(X3);
+  out.Y = typename CV::XY(Y3);
+  out.ZZ = typename CV::XZZ(mul(mul(p.ZZ, q.ZZ), PP));
+  out.ZZZ = typename CV::XZZZ(mul(mul(p.ZZZ, q.ZZZ), PPP));
+  return out;
+}
+
 // XYZZ -> Jacobian with Z = ZZ:  (X*ZZ, Y*ZZZ, ZZ)   [Y*ZZ^3/ZZZ = Y*ZZZ since ZZ^3 = ZZZ^2]
 template <class CV>
 OZK_HD Jac<CV> xyzz_to_jac(const Xyzz<CV>& p) {

@@ -208,12 +208,46 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sort1_count(const uint16_t* __re
 }
 
 // coarse[P1[(w*NH+h)*nblk + blk] + rank] = (i << 8) | lo
+// The chunk is first sorted by hi inside LDS and then written out in bin order: consecutive lanes
+// write consecutive words of a bin (runs of ~16 words per bin and block = one 64-byte request
+// instead of 16 four-byte ones; the scattered form was bound by the L2 request rate).
 __global__ void __launch_bounds__(SORT_BLOCK) k_sort1_scatter(const uint16_t* __restrict__ digits, int n, int lo_bits,
                                                               int NH, int nblk, const u32* __restrict__ P1,
+                                                              const u32* __restrict__ total, size_t nC1,
                                                               u32* __restrict__ coarse) {
-  extern __shared__ u32 cnt[];
+  extern __shared__ u32 sm[];
+  u32* gdelta = sm;            // [NH] global start of (bin, block) minus its local start
+  u32* lcur = sm + NH;         // [NH] local cursor
+  u32* stage = sm + 2 * NH;    // [SORT_CHUNK] packed entries in bin order
+  u32* dest = stage + SORT_CHUNK;  // [SORT_CHUNK] their positions in coarse[]
+  __shared__ u32 wsum[SORT_BLOCK / 64];
+  __shared__ u32 n_local;
   const int w = blockIdx.y, blk = blockIdx.x;
-  for (int h = threadIdx.x; h < NH; h += SORT_BLOCK) cnt[h] = P1[((size_t)w * NH + h) * nblk + blk];
+  const int t = threadIdx.x;
+  // NH <= 256 = SORT_BLOCK (c <= 16): one bin per thread
+  u32 g0 = 0, ct = 0;
+  if (t < NH) {
+    const size_t idx = ((size_t)w * NH + t) * nblk + blk;
+    g0 = P1[idx];
+    ct = ((idx + 1 < nC1) ? P1[idx + 1] : *total) - g0;
+  }
+  u32 incl = ct;
+  const int lane = t & 63;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const u32 x = __shfl_up(incl, o);
+    if (lane >= o) incl += x;
+  }
+  if (lane == 63) wsum[t >> 6] = incl;
+  __syncthreads();
+  u32 woff = 0;
+  for (int k = 0; k < (t >> 6); k++) woff += wsum[k];
+  const u32 excl = woff + incl - ct;
+  if (t < NH) {
+    lcur[t] = excl;
+    gdelta[t] = g0 - excl;
+  }
+  if (t == SORT_BLOCK - 1) n_local = woff + incl;
   __syncthreads();
   const int i0 = blk * SORT_CHUNK;
   const u32 lo_mask = (1u << lo_bits) - 1u;
@@ -228,9 +262,16 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sort1_scatter(const uint16_t* __
   for (int k = 0; k < PER; k++) {
     const int i = i0 + k * SORT_BLOCK + threadIdx.x;
     const bool live = dreg[k] != 0;
-    const u32 pos = lds_rank(cnt, dreg[k] >> lo_bits, live);
-    if (live) coarse[pos] = ((u32)i << 8) | (dreg[k] & lo_mask);
+    const u32 hi = dreg[k] >> lo_bits;
+    const u32 r = lds_rank(lcur, hi, live);
+    if (live) {
+      stage[r] = ((u32)i << 8) | (dreg[k] & lo_mask);
+      dest[r] = r + gdelta[hi];
+    }
   }
+  __syncthreads();
+  const u32 m = n_local;
+  for (u32 j = t; j < m; j += SORT_BLOCK) coarse[dest[j]] = stage[j];
 }
 
 // Coarse bins above max(SORT_BIG, n/64) entries (skewed digits: the reference's own profiler inputs put half
@@ -646,7 +687,14 @@ k_segreduce(const u32* __restrict__ bid_in, const u32* __restrict__ idx_in,
         acc.store(pts_out + (size_t)(2 * (size_t)t) * IO::REC_WORDS);
         if (cf) {  // cut on both sides: neutral element keeps the pieces adjacent
           tail_bid = cur;
-          IO::store_rec_jac(jac_infinity<CV>(), pts_out + (size_t)(2 * (size_t)t + 1) * IO::REC_WORDS);
+          if constexpr (FIRST) {
+            Xyzz<CV> z = acc.a;
+            z.ZZ = typename CV::XZZ(el_zero(z.ZZ));
+            z.ZZZ = typename CV::XZZZ(el_zero(z.ZZ));
+            IO::store_rec_xyzz(z, pts_out + (size_t)(2 * (size_t)t + 1) * IO::REC_WORDS);
+          } else {
+            IO::store_rec_jac(jac_infinity<CV>(), pts_out + (size_t)(2 * (size_t)t + 1) * IO::REC_WORDS);
+          }
         }
       } else if (cf) {
         tail_bid = cur;
@@ -689,9 +737,11 @@ k_runmerge(const u32* __restrict__ bid_in, const u32* __restrict__ pts, int n_sl
       if (!is_short) {
         out = bx;
       } else if (s == x) {  // owner of the run: sum it
-        Jac<CV> acc = IO::load_rec(pts + (size_t)s * IO::REC_WORDS);
-        for (int q = s + 1; q <= e; q++) acc = jac_add(acc, IO::load_rec(pts + (size_t)q * IO::REC_WORDS));
-        IO::store_rec_jac(acc, buckets + (size_t)bx * IO::REC_WORDS);
+        // level-1 pieces are all XYZZ records (the neutral placeholder of a chunk cut on both sides
+        // included): 12M + 2S general additions, no conversion
+        Xyzz<CV> acc = IO::load_xyzz(pts + (size_t)s * IO::REC_WORDS);
+        for (int q = s + 1; q <= e; q++) acc = xyzz_add(acc, IO::load_xyzz(pts + (size_t)q * IO::REC_WORDS));
+        IO::store_rec_xyzz(acc, buckets + (size_t)bx * IO::REC_WORDS);
       }
     }
     bid_out[x] = out;

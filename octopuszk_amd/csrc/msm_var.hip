@@ -213,8 +213,9 @@ static int var_msm_sort(const void* d_bases, const void* d_scalars, int n, void*
   hipLaunchKernelGGL(k_scan_blocksum, dim3(nb), dim3(SCAN_BLOCK), 0, st, L.C1, (int)L.nC1, L.blocksum);
   hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, L.blocksum, nb, L.total);
   hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_BLOCK), 0, st, L.C1, (int)L.nC1, L.blocksum, L.P1);
-  hipLaunchKernelGGL(k_sort1_scatter, dim3(L.nblk, p.W), dim3(SORT_BLOCK), lds1, st, L.digits, n, L.lo_bits, L.NH,
-                     L.nblk, L.P1, L.coarse);
+  const size_t lds_sc = ((size_t)2 * L.NH + 2 * SORT_CHUNK) * sizeof(u32);
+  hipLaunchKernelGGL(k_sort1_scatter, dim3(L.nblk, p.W), dim3(SORT_BLOCK), lds_sc, st, L.digits, n, L.lo_bits, L.NH,
+                     L.nblk, L.P1, L.total, L.nC1, L.coarse);
   const int nbins = p.W * L.NH;
   const u32 big_thresh = (u32)(n / 64) > SORT_BIG ? (u32)(n / 64) : SORT_BIG;
   hipLaunchKernelGGL(k_sort2, dim3(nbins), dim3(SORT_BLOCK), 0, st, L.coarse, L.P1, L.total, p.c, L.lo_bits, L.NH,

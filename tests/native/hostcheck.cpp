@@ -69,6 +69,18 @@ extern "C" void hc_g1_op(int op, const u32* pw, const u32* qw, int k, u32* out) 
       r = xyzz_to_jac(a);
       break;
     }
+    case 8: case 9: case 10: case 11: {  // general XYZZ addition: A = P + kQ, B = Q + kP (both with ZZ != 1)
+      Aff<A1> pa; pa.x = A1(reduce_to<17>(p.X)); pa.y = A1(reduce_to<17>(p.Y));
+      Xyzz<J1> a = xyzz_from_affine<J1>(pa), b = xyzz_from_affine<J1>(qa);
+      for (int i = 0; i < k; i++) { a = xyzz_madd(a, qa); b = xyzz_madd(b, pa); }
+      Xyzz<J1> z = a; z.ZZ = J1::XZZ(el_zero(pa.x)); z.ZZZ = J1::XZZZ(el_zero(pa.x));
+      Xyzz<J1> na = a; na.Y = J1::XY(reduce_to<32>(neg(reduce_to<32>(a.Y))));
+      if (op == 8) r = xyzz_to_jac(xyzz_add(a, b));                 // (k+1)(P+Q)
+      else if (op == 9) r = xyzz_to_jac(xyzz_add(a, a));            // doubling branch: 2(P+kQ)
+      else if (op == 10) r = xyzz_to_jac(xyzz_add(a, na));          // infinity
+      else r = xyzz_to_jac(xyzz_add(xyzz_add(z, a), z));            // infinity on either side: P+kQ
+      break;
+    }
     default: r = p;
   }
   store_jac(r, out);
@@ -108,6 +120,18 @@ extern "C" void hc_g2_op(int op, const u32* pw, const u32* qw, int k, u32* out) 
       Xyzz<J2> a = xyzz_from_affine<J2>(pa);
       for (int i = 0; i < k; i++) a = xyzz_madd(a, qa);
       r = xyzz_to_jac(a);
+      break;
+    }
+    case 8: case 9: case 10: case 11: {  // general XYZZ addition: A = P + kQ, B = Q + kP (both with ZZ != 1)
+      Aff<J2::EA> pa; pa.x = J2::EA(reduce_to<17>(p.X)); pa.y = J2::EA(reduce_to<17>(p.Y));
+      Xyzz<J2> a = xyzz_from_affine<J2>(pa), b = xyzz_from_affine<J2>(qa);
+      for (int i = 0; i < k; i++) { a = xyzz_madd(a, qa); b = xyzz_madd(b, pa); }
+      Xyzz<J2> z = a; z.ZZ = J2::XZZ(el_zero(pa.x)); z.ZZZ = J2::XZZZ(el_zero(pa.x));
+      Xyzz<J2> na = a; na.Y = J2::XY(reduce_to<32>(neg(reduce_to<32>(a.Y))));
+      if (op == 8) r = xyzz_to_jac(xyzz_add(a, b));                 // (k+1)(P+Q)
+      else if (op == 9) r = xyzz_to_jac(xyzz_add(a, a));            // doubling branch: 2(P+kQ)
+      else if (op == 10) r = xyzz_to_jac(xyzz_add(a, na));          // infinity
+      else r = xyzz_to_jac(xyzz_add(xyzz_add(z, a), z));            // infinity on either side: P+kQ
       break;
     }
     default: r = p;

@@ -118,6 +118,14 @@ def test_g1_group_law(hc):
     assert G.equals(g1_op(hc, 7, Pa, G.negate(Pa), 2), G.negate(P))
     assert G.equals(g1_op(hc, 7, G.zero, aff[2], 3), G.mul(aff[2], 3))
     assert G.equals(g1_op(hc, 7, Pa, G.zero, 4), P)
+    # general XYZZ + XYZZ (level-1 in-wave merge): generic, doubling, cancellation, infinity
+    Qa = aff[1]
+    assert G.equals(g1_op(hc, 8, Pa, Qa, 7), G.mul(G.add(P, Qa), 8))
+    assert G.equals(g1_op(hc, 9, Pa, Qa, 7), G.twice(G.add(P, G.mul(Qa, 7))))
+    assert G.is_zero(g1_op(hc, 10, Pa, Qa, 7))
+    assert G.equals(g1_op(hc, 11, Pa, Qa, 7), G.add(P, G.mul(Qa, 7)))
+    assert G.equals(g1_op(hc, 8, Pa, Qa, 0), G.add(P, Qa))          # ZZ == 1 on both sides
+    assert G.equals(g1_op(hc, 8, Pa, Pa, 3), G.mul(P, 8))           # A == B: doubling inside the add
     # CurvesTest.java:27-82 identities on the HIP group law
     a = pts[3]
     assert G.equals(g1_op(hc, 0, G.mul(a, 76749407), G.mul(a, 44410867)), G.mul(a, 121160274))
@@ -184,3 +192,9 @@ def test_g2_group_law(hc):
     assert G.equals(g2_op(hc, 7, Pa, aff[1], 60), G.add(P, G.mul(aff[1], 60)))
     assert G.equals(g2_op(hc, 7, Pa, Pa, 3), G.mul(P, 4))
     assert G.is_zero(g2_op(hc, 7, Pa, G.negate(Pa), 1))
+    Qa = aff[1]
+    assert G.equals(g2_op(hc, 8, Pa, Qa, 5), G.mul(G.add(P, Qa), 6))
+    assert G.equals(g2_op(hc, 9, Pa, Qa, 5), G.twice(G.add(P, G.mul(Qa, 5))))
+    assert G.is_zero(g2_op(hc, 10, Pa, Qa, 5))
+    assert G.equals(g2_op(hc, 11, Pa, Qa, 5), G.add(P, G.mul(Qa, 5)))
+    assert G.equals(g2_op(hc, 8, Pa, Pa, 2), G.mul(P, 6))
