@@ -809,6 +809,31 @@ __device__ __forceinline__ Jac<CV> shfl_down_jac(const Jac<CV>& p, int o) {
   return r;
 }
 
+// lanes l < valid hold element l = (A, T := R); returns (A', R') of the 64x coarser element in lane 0
+template <class CV>
+__device__ __forceinline__ void wave_combine(Jac<CV>& A, Jac<CV>& T, int l, int valid, int g) {
+  // suffix scan of R
+  for (int o = 1; o < valid; o <<= 1) {
+    const Jac<CV> t = shfl_down_jac(T, o);
+    const Jac<CV> s = jac_add(T, t);
+    if (l + o < 64) T = s;
+  }
+  // V = A + 2^g * (l >= 1 ? T : inf)
+  Jac<CV> U = T;
+  for (int k = 0; k < g; k++) U = jac_dbl(U);
+  const Jac<CV> AV = jac_add(A, U);
+  Jac<CV> V = (l >= 1) ? AV : A;
+  // tree reduction of V
+  int top = 1;
+  while (top < valid) top <<= 1;
+  for (int o = top >> 1; o > 0; o >>= 1) {
+    const Jac<CV> v = shfl_down_jac(V, o);
+    const Jac<CV> s = jac_add(V, v);
+    if (l < o) V = s;
+  }
+  A = V;
+}
+
 template <class CV>
 __global__ void __launch_bounds__(64)
 k_wsum_wave(const u32* __restrict__ A_in, const u32* __restrict__ R_in, int m_in, int g,
@@ -830,28 +855,44 @@ k_wsum_wave(const u32* __restrict__ A_in, const u32* __restrict__ R_in, int m_in
     A = IO::load_jac(A_in + ((size_t)w * m_in + e) * IO::JAC_WORDS);
     T = IO::load_jac(R_in + ((size_t)w * m_in + e) * IO::JAC_WORDS);
   }
-  // suffix scan of R
-  for (int o = 1; o < valid; o <<= 1) {
-    const Jac<CV> t = shfl_down_jac(T, o);
-    const Jac<CV> s = jac_add(T, t);
-    if (l + o < 64) T = s;
-  }
-  // V = A + 2^g * (l >= 1 ? T : inf)
-  Jac<CV> U = T;
-  for (int k = 0; k < g; k++) U = jac_dbl(U);
-  const Jac<CV> AV = jac_add(A, U);
-  Jac<CV> V = (l >= 1) ? AV : A;
-  // tree reduction of V
-  int top = 1;
-  while (top < valid) top <<= 1;
-  for (int o = top >> 1; o > 0; o >>= 1) {
-    const Jac<CV> v = shfl_down_jac(V, o);
-    const Jac<CV> s = jac_add(V, v);
-    if (l < o) V = s;
-  }
+  wave_combine<CV>(A, T, l, valid, g);
   if (l == 0) {
-    IO::store_jac(V, A_out + ((size_t)w * m_out + j) * IO::JAC_WORDS);
+    IO::store_jac(A, A_out + ((size_t)w * m_out + j) * IO::JAC_WORDS);
     IO::store_jac(T, R_out + ((size_t)w * m_out + j) * IO::JAC_WORDS);
+  }
+}
+
+// Fused first level: every lane sums S consecutive buckets serially (as k_wsum<FIRSTLEVEL>), then the
+// wave combines its 64 lane results while they are still in registers: 64 S buckets -> one element,
+// no intermediate round trip and one launch less on the critical path of the window sums
+// (2 S + 13 dependent additions for a 64 S-fold reduction; the unfused pair needed 2 S + 13 for S x 64
+// too, but as two latency-bound kernels with a 2^c / S-element hand-off).
+template <class CV>
+__global__ void __launch_bounds__(64)
+k_wsum_fused(const u32* __restrict__ buckets, const u32* __restrict__ hist, int m_in, int S, int sg,
+             u32* __restrict__ A_out, u32* __restrict__ R_out, int m_out, int W, int prio) {
+  using IO = CurveIO<CV>;
+  if (prio) __builtin_amdgcn_s_setprio(3);
+  const int wave = blockIdx.x;
+  if (wave >= m_out * W) return;
+  const int w = wave / m_out, j = wave - w * m_out;
+  const int l = threadIdx.x & 63;
+  const int nseg = (m_in + S - 1) / S;  // segments of this window
+  int valid = nseg - j * 64;
+  if (valid > 64) valid = 64;
+  const size_t base = (size_t)w * m_in;
+  const int lo = (j * 64 + l) * S;
+  int hi = lo + S;
+  if (hi > m_in) hi = m_in;
+  Jac<CV> run = jac_infinity<CV>(), ws = jac_infinity<CV>();
+  for (int e = hi - 1; e >= lo; e--) {  // (empty for lanes past the window's end)
+    if (hist[base + e] != 0) run = jac_add(run, IO::load_rec(buckets + (base + e) * IO::REC_WORDS));
+    if (e > lo) ws = jac_add(ws, run);  // after the loop: sum (e - lo) * B_e
+  }
+  wave_combine<CV>(ws, run, l, valid, sg);
+  if (l == 0) {
+    IO::store_jac(ws, A_out + ((size_t)w * m_out + j) * IO::JAC_WORDS);
+    IO::store_jac(run, R_out + ((size_t)w * m_out + j) * IO::JAC_WORDS);
   }
 }
 
@@ -885,9 +926,11 @@ __device__ void write_normalised(const Jac<CV>& r, u32* out) {
 // declaring all 512 VGPRs; wave 0 works, the other three sleep until it is done.  The accumulation
 // kernel then loses 1 CU of 256 instead of 20 % of its time — experimental, see msm_var.hip.
 template <class CV, bool EXCLUSIVE>
-__global__ void __launch_bounds__(256) k_finalize(const u32* __restrict__ A_w, int W, int c, u32* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_finalize(const u32* __restrict__ A_w, const u32* __restrict__ R_w, int m,
+                                                  int g, int W, int c, u32* __restrict__ out) {
   using IO = CurveIO<CV>;
   __shared__ volatile int done;
+  __shared__ u32 sw[64 * IO::JAC_WORDS];  // S_w of up to 64 windows at a time
   if constexpr (EXCLUSIVE) {
     // 256 VGPRs + 256 AGPRs = the SIMD's whole register file
     asm volatile("v_mov_b32 v255, 0\n\tv_accvgpr_write_b32 a255, 0" ::: "v255", "a255");
@@ -899,14 +942,41 @@ __global__ void __launch_bounds__(256) k_finalize(const u32* __restrict__ A_w, i
     while (!done) __builtin_amdgcn_s_sleep(64);
     return;
   }
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_s_setprio(3);
-    A_w += opaque_zero();
-    Jac<CV> r = jac_infinity<CV>();
-    for (int w = W - 1; w >= 0; w--) {
-      for (int k = 0; k < c; k++) r = jac_dbl(r);  // no-op while r is infinity
-      r = jac_add(r, IO::load_jac(A_w + (size_t)w * IO::JAC_WORDS));
+  __builtin_amdgcn_s_setprio(3);
+  // The last window-sum level left m (<= a few) elements (A_j, R_j) per window:
+  //     S_w = sum_j A_j + 2^g * sum_j j * R_j
+  // — lane w finishes window w (all windows in parallel), then lane 0 runs Horner over the S_w.
+  const int l = threadIdx.x;
+  Jac<CV> r = jac_infinity<CV>();
+  for (int w0 = ((W - 1) / 64) * 64; w0 >= 0; w0 -= 64) {  // (W <= 64 unless the window size is forced tiny)
+    const int w = w0 + l;
+    if (w < W) {
+      Jac<CV> run = jac_infinity<CV>(), acc = jac_infinity<CV>(), asum = jac_infinity<CV>();
+      for (int j = m - 1; j >= 0; j--) {
+        asum = jac_add(asum, IO::load_jac(A_w + ((size_t)w * m + j) * IO::JAC_WORDS));
+        if (j >= 1) {
+          run = jac_add(run, IO::load_jac(R_w + ((size_t)w * m + j) * IO::JAC_WORDS));
+          acc = jac_add(acc, run);
+        }
+      }
+      if (m > 1) {
+        for (int k = 0; k < g; k++) acc = jac_dbl(acc);
+        asum = jac_add(asum, acc);
+      }
+      IO::store_jac(asum, sw + (size_t)l * IO::JAC_WORDS);
     }
+    __builtin_amdgcn_wave_barrier();
+    if (l == 0) {
+      const u32* sp = sw + opaque_zero();
+      const int top = (W - w0 < 64) ? (W - w0) : 64;
+      for (int i = top - 1; i >= 0; i--) {
+        for (int k = 0; k < c; k++) r = jac_dbl(r);  // no-op while r is infinity
+        r = jac_add(r, IO::load_jac(sp + (size_t)i * IO::JAC_WORDS));
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (l == 0) {
     write_normalised<CV>(r, out);
     done = 1;
   }

@@ -46,7 +46,7 @@ static MsmPlan make_plan(int n) {
   p.LK = env_int("OZK_MSM_LK", 16);
   if (p.L1 < 2) p.L1 = 2;
   if (p.LK < 4) p.LK = 4;
-  int S = env_int("OZK_MSM_S", 16);
+  int S = env_int("OZK_MSM_S", 4);
   int sg = ilog2((uint32_t)(S < 2 ? 2 : S));
   p.S = 1 << sg;
   return p;
@@ -159,21 +159,42 @@ static size_t tail_layout(const MsmPlan& p, MsmLayout& L, void* tail, size_t tai
   return b.off;
 }
 
-// First window-sum level: S buckets per lane, W * 2^c / S lanes.  Only 2 waves per CU at 2^20, so it
-// is latency-bound (32 dependent additions).  It closes the HEAD phase by default.  Measured with
-// two MSMs in flight: opening the TAIL with it instead (OZK_MSM_WSUM0_IN_TAIL=1, where it overlaps
-// the next MSM's bucket accumulation) is SLOWER, 353 vs 395 Mscalar-mul/s — its 512 prioritised
-// waves take a full share of the multiplier issue slots of half the SIMDs and stretch the level-1
-// kernel from 1.36 to 1.50 ms; overlapped work is not free, only its latency is hidden.
-static bool wsum0_in_tail() { return env_int("OZK_MSM_WSUM0_IN_TAIL", 0) != 0; }
+// First window-sum level.  Fused form (default): a lane sums S = 4 buckets, its wave combines the 64
+// lane results in registers -> W * 2^c / 256 elements.  Everything after the bucket accumulation is
+// multiplier-issue work spread over few waves, so WHERE it runs matters more than how deep it is
+// (measured at 2^20, two MSMs in flight, Mscalar-mul/s / single-MSM ms):
+//     unfused S=16, closing the head phase                      444-447 / 3.40-3.44
+//     fused S=4, opening the tail phase, no issue priority      461-465 / 3.48-3.64   <- default
+//     fused S=16 / unfused S=8 in the tail, with or without priority: 372-420 (their 512-1024 waves
+//     sit on the same SIMDs as the next MSM's bucket accumulation and stretch it 1.35 -> 1.5-1.9 ms)
+static bool wsum0_in_tail() { return env_int("OZK_MSM_WSUM0_IN_TAIL", 1) != 0; }
+static bool wsum_fused() { return env_int("OZK_MSM_WSUM_FUSED", 1) != 0; }
+// elements per window the first level leaves, and the g (log2 of buckets per element) they carry
+static void first_level_shape(const MsmPlan& p, int* m_out, int* g_out) {
+  const int m_in = 1 << p.c;
+  const int nseg = (m_in + p.S - 1) / p.S;
+  const int sg = ilog2((uint32_t)p.S);
+  if (wsum_fused()) {
+    *m_out = (nseg + 63) / 64;
+    *g_out = sg + 6;
+  } else {
+    *m_out = nseg;
+    *g_out = sg;
+  }
+}
 template <class CV>
 static void launch_wsum0(const MsmPlan& p, const MsmLayout& L, hipStream_t st, int prio) {
   const int TB = 256;
   const int m_in = 1 << p.c;
-  const int m_out = (m_in + p.S - 1) / p.S;
+  int m_out, g;
+  first_level_shape(p, &m_out, &g);
   const int tot = m_out * p.W;
-  hipLaunchKernelGGL((k_wsum<CV, true>), dim3((tot + TB - 1) / TB), dim3(TB), 0, st, (const u32*)nullptr,
-                     L.buckets, L.hist_t, m_in, p.S, 0, L.wA[0], L.wR[0], m_out, p.W, prio);
+  if (wsum_fused())
+    hipLaunchKernelGGL((k_wsum_fused<CV>), dim3(tot), dim3(64), 0, st, L.buckets, L.hist_t, m_in, p.S,
+                       ilog2((uint32_t)p.S), L.wA[0], L.wR[0], m_out, p.W, prio);
+  else
+    hipLaunchKernelGGL((k_wsum<CV, true>), dim3((tot + TB - 1) / TB), dim3(TB), 0, st, (const u32*)nullptr,
+                       L.buckets, L.hist_t, m_in, p.S, 0, L.wA[0], L.wR[0], m_out, p.W, prio);
 }
 
 // SORT stage: bases -> affine Montgomery, digits, two-level counting sort.  Memory / LDS-bound;
@@ -303,8 +324,9 @@ static int var_msm_tail(int n, void* tail, size_t tail_bytes, void* d_out, hipSt
   L.m1 = (((size_t)1 << p.c) + p.S - 1) / p.S;
   const size_t tneed = tail_layout<CV>(p, L, tail, tail_bytes);
   if (tneed > tail_bytes) return fail(OZK_E_INVALID, "tail buffer too small: need %zu bytes, got %zu", tneed, tail_bytes);
-  if (wsum0_in_tail()) launch_wsum0<CV>(p, L, st, env_int("OZK_MSM_WSUM0_PRIO", 1));
-  int m_in = (int)L.m1, g = ilog2((uint32_t)p.S), k = 0;
+  if (wsum0_in_tail()) launch_wsum0<CV>(p, L, st, env_int("OZK_MSM_WSUM0_PRIO", 0));
+  int m_in, g, k = 0;
+  first_level_shape(p, &m_in, &g);
   const int TB = 256;
   const int sg = ilog2((uint32_t)p.S);
   // Optional serial S-per-lane levels first (3 additions per element instead of the wave form's
@@ -321,7 +343,11 @@ static int var_msm_tail(int n, void* tail, size_t tail_bytes, void* d_out, hipSt
     g += sg;
     k ^= 1;
   }
-  while (m_in > 1) {
+  // wave-cooperative levels until a handful of elements per window is left; k_finalize finishes those
+  int fin_max = env_int("OZK_MSM_FIN_MAX", 4);
+  if (fin_max < 1) fin_max = 1;
+  if (fin_max > 16) fin_max = 16;
+  while (m_in > fin_max) {
     const int m_out = (m_in + 63) / 64;
     const int tot = m_out * p.W;
     hipLaunchKernelGGL((k_wsum_wave<CT>), dim3(tot), dim3(64), 0, st, L.wA[k], L.wR[k], m_in, g, L.wA[k ^ 1],
@@ -336,9 +362,11 @@ static int var_msm_tail(int n, void* tail, size_t tail_bytes, void* d_out, hipSt
   // created and destroyed before it (suspected: mid-wave preemption of 512-register waves under
   // queue oversubscription), so it is not the default.
   if (env_int("OZK_FINALIZE_EXCLUSIVE", 0))
-    hipLaunchKernelGGL((k_finalize<CT, true>), dim3(1), dim3(256), 0, st, L.wA[k], p.W, p.c, (u32*)d_out);
+    hipLaunchKernelGGL((k_finalize<CT, true>), dim3(1), dim3(256), 0, st, L.wA[k], L.wR[k], m_in, g, p.W, p.c,
+                       (u32*)d_out);
   else
-    hipLaunchKernelGGL((k_finalize<CT, false>), dim3(1), dim3(256), 0, st, L.wA[k], p.W, p.c, (u32*)d_out);
+    hipLaunchKernelGGL((k_finalize<CT, false>), dim3(1), dim3(256), 0, st, L.wA[k], L.wR[k], m_in, g, p.W, p.c,
+                       (u32*)d_out);
   OZK_HIP(hipGetLastError());
   return OZK_OK;
 }
