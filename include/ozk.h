@@ -74,6 +74,20 @@ int ozk_var_msm_dev(const void* d_bases, const void* d_scalars, int32_t n, int32
  * normalisation; a few lanes busy for ~2 ms) and reads nothing but `d_tail`.  Running the tail
  * on a second stream lets the next MSM's head (which may reuse the same workspace) overlap
  * it.  ozk_var_msm_dev == head + tail on one stream. */
+/* Ordering hint for several MSMs in flight on two streams.  The bucket accumulation of MSM k+1 fills
+ * every SIMD's register file; if it is dispatched before the single-wave Horner kernel of MSM k is
+ * resident, that kernel waits for a free slot (+0.7 ms) and then starves the accumulation blocks next
+ * to it (measured: 447 -> 370 Mscalar-mul/s).  `tail_ordered` records `levels_done` after its multi-wave
+ * window-sum levels, right before the Horner kernel; `head_ordered` waits for it after its sort and
+ * before its accumulation.  Events come from ozk_order_event_create (a HIP event underneath). */
+int ozk_order_event_create(void** ev);
+int ozk_order_event_destroy(void* ev);
+int ozk_var_msm_head_ordered_dev(const void* d_bases, const void* d_scalars, int32_t n, int32_t type,
+                                 void* d_workspace, size_t workspace_bytes, void* d_tail, size_t tail_bytes,
+                                 void* stream, void* previous_levels_done);
+int ozk_var_msm_tail_ordered_dev(int32_t n, int32_t type, void* d_tail, size_t tail_bytes, void* d_out, void* stream,
+                                 void* levels_done);
+
 /* The head itself has two stages that stress different units — SORT (base conversion, digits,
  * counting sort: HBM / LDS) and ACCUMULATE (bucket accumulation ... first window-sum level:
  * vector ALU) — so a caller may pipeline three stages (sort of MSM k+2 | accumulate of k+1 |

@@ -113,6 +113,15 @@ OZK_HD auto mul(const Fe<P, B1>& a, const Fe<P, B2>& b) {
   return r;
 }
 
+// c ? a : b, limb-wise (v_cndmask)
+template <class P, int B>
+OZK_HD Fe<P, B> select_el(bool c, const Fe<P, B>& a, const Fe<P, B>& b) {
+  Fe<P, B> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = c ? a.l[i] : b.l[i];
+  return r;
+}
+
 // multiplication by a base-field constant; overloaded component-wise for Fq2 (fq2.cuh)
 template <class P, int B1>
 OZK_HD auto scale(const Fe<P, B1>& a, const Fe<P, 16>& k) { return mul(a, k); }

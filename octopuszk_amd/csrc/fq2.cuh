@@ -107,6 +107,13 @@ OZK_HD Fe2<32> mul(const Fe2<B1>& a_in, const Fe2<B2>& b_in) {
     return r;
   }
 }
+template <int B>
+OZK_HD Fe2<B> select_el(bool c, const Fe2<B>& a, const Fe2<B>& b) {
+  Fe2<B> r;
+  r.c0 = select_el(c, a.c0, b.c0);
+  r.c1 = select_el(c, a.c1, b.c1);
+  return r;
+}
 template <int B1>
 OZK_HD Fe2<32> scale(const Fe2<B1>& a, const Fe<FqParams, 16>& k) {
   Fe2<32> r;

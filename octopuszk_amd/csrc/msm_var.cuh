@@ -34,7 +34,9 @@ struct MsmPlan {
   int n_in;     // (scalar, base) pairs handed in
   int glv;      // 1: every pair is split into two half-length pairs by the GLV endomorphism (glv.cuh)
   int n;        // points the pipeline sorts and accumulates: n_in, or 2 * n_in with GLV
+  int sd;       // 1: signed digits in (-2^(c-1), 2^(c-1)] (GLV mode only): half the buckets per window
   int c;        // window bits (<= 16)
+  int cb;       // bucket-index bits per window: c, or c - 1 with signed digits
   int W;        // windows = ceil(256 / c), or ceil(128 / c) with GLV
   int L1;       // sorted entries per lane at level 1
   int LK;       // slots per lane at levels >= 2
@@ -48,6 +50,24 @@ OZK_HD u32 scalar_digit(const u32 (&s)[8], int w, int c) {
   if (sh + c > 32 && wi + 1 < 8) v |= s[wi + 1] << (32 - sh);
   return v & ((1u << c) - 1u);
 }
+
+// Digit codes (u16, 0 = zero digit, skipped).  Unsigned windows: code = digit d, bucket index b = d,
+// weight b.  Signed windows: d in (-2^(c-1), 2^(c-1)], code = (((|d| - 1) << 1) | (d < 0)) + 1, bucket
+// index b = |d| - 1 < 2^(c-1), weight b + 1; the point is subtracted when d < 0.
+OZK_HD bool digit_decode(u32 code, int sd, u32& b, u32& neg) {
+  if (sd) {
+    const u32 t = code - 1u;
+    b = t >> 1;
+    neg = t & 1u;
+  } else {
+    b = code;
+    neg = 0;
+  }
+  return code != 0;
+}
+// Packed coarse word: index << 8 | lo8, lo8 = low bucket bits (8 unsigned / 7 signed) | neg << 7 (signed).
+// In the sorted index array the sign travels in bit 31.
+constexpr u32 SIDX_NEG = 0x80000000u;
 
 #if defined(__HIPCC__)
 
@@ -129,7 +149,7 @@ __global__ void __launch_bounds__(256) k_digits(const u32* __restrict__ scalars,
 // GLV form: scalar i (reduced mod r) -> |k1|, |k2| < 2^127 (glv.cuh); virtual scalar i = |k1| and
 // n + i = |k2| of a 2n-point MSM with W = ceil(128 / c) windows; the signs go to neg_flags for
 // k_convert_bases.
-__global__ void __launch_bounds__(256) k_digits_glv(const u32* __restrict__ scalars, int n, int c, int W,
+__global__ void __launch_bounds__(256) k_digits_glv(const u32* __restrict__ scalars, int n, int c, int W, int sd,
                                                     uint16_t* __restrict__ digits, uint8_t* __restrict__ neg_flags) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -144,9 +164,23 @@ __global__ void __launch_bounds__(256) k_digits_glv(const u32* __restrict__ scal
   u32 e1[8] = {k1[0], k1[1], k1[2], k1[3], 0, 0, 0, 0};
   u32 e2[8] = {k2[0], k2[1], k2[2], k2[3], 0, 0, 0, 0};
   const size_t ne = 2 * (size_t)n;
-  for (int w = 0; w < W; w++) {
-    digits[(size_t)w * ne + i] = (uint16_t)scalar_digit(e1, w, c);
-    digits[(size_t)w * ne + n + i] = (uint16_t)scalar_digit(e2, w, c);
+  if (sd) {
+    // carry-propagated signed digits; |k| < 2^127 (glv.cuh) keeps the top digit within (-2^(c-1), 2^(c-1)]
+    const u32 half = 1u << (c - 1);
+    u32 cy1 = 0, cy2 = 0;
+    for (int w = 0; w < W; w++) {
+      u32 d1 = scalar_digit(e1, w, c) + cy1, d2 = scalar_digit(e2, w, c) + cy2;
+      cy1 = d1 > half;
+      cy2 = d2 > half;
+      const u32 m1 = cy1 ? (1u << c) - d1 : d1, m2 = cy2 ? (1u << c) - d2 : d2;
+      digits[(size_t)w * ne + i] = (uint16_t)(m1 ? (((m1 - 1u) << 1) | cy1) + 1u : 0u);
+      digits[(size_t)w * ne + n + i] = (uint16_t)(m2 ? (((m2 - 1u) << 1) | cy2) + 1u : 0u);
+    }
+  } else {
+    for (int w = 0; w < W; w++) {
+      digits[(size_t)w * ne + i] = (uint16_t)scalar_digit(e1, w, c);
+      digits[(size_t)w * ne + n + i] = (uint16_t)scalar_digit(e2, w, c);
+    }
   }
   neg_flags[i] = n1;
   neg_flags[n + i] = n2;
@@ -188,7 +222,7 @@ __device__ __forceinline__ u32 lds_rank(u32* cnt, u32 key, bool live) {
 
 // C1[(w*NH + h)*nblk + blk] = number of non-zero digits with hi value h in this block's chunk
 __global__ void __launch_bounds__(SORT_BLOCK) k_sort1_count(const uint16_t* __restrict__ digits, int n, int lo_bits,
-                                                            int NH, int nblk, u32* __restrict__ C1) {
+                                                            int sd, int NH, int nblk, u32* __restrict__ C1) {
   extern __shared__ u32 cnt[];
   const int w = blockIdx.y, blk = blockIdx.x;
   for (int h = threadIdx.x; h < NH; h += SORT_BLOCK) cnt[h] = 0;
@@ -202,17 +236,21 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sort1_count(const uint16_t* __re
     dreg[k] = (i < n) ? digits[(size_t)w * n + i] : 0u;
   }
 #pragma unroll
-  for (int k = 0; k < PER; k++) lds_rank(cnt, dreg[k] >> lo_bits, dreg[k] != 0);
+  for (int k = 0; k < PER; k++) {
+    u32 b, neg;
+    const bool live = digit_decode(dreg[k], sd, b, neg);
+    lds_rank(cnt, b >> lo_bits, live);
+  }
   __syncthreads();
   for (int h = threadIdx.x; h < NH; h += SORT_BLOCK) C1[((size_t)w * NH + h) * nblk + blk] = cnt[h];
 }
 
-// coarse[P1[(w*NH+h)*nblk + blk] + rank] = (i << 8) | lo
+// coarse[P1[(w*NH+h)*nblk + blk] + rank] = (i << 8) | lo8
 // The chunk is first sorted by hi inside LDS and then written out in bin order: consecutive lanes
 // write consecutive words of a bin (runs of ~16 words per bin and block = one 64-byte request
 // instead of 16 four-byte ones; the scattered form was bound by the L2 request rate).
 __global__ void __launch_bounds__(SORT_BLOCK) k_sort1_scatter(const uint16_t* __restrict__ digits, int n, int lo_bits,
-                                                              int NH, int nblk, const u32* __restrict__ P1,
+                                                              int sd, int NH, int nblk, const u32* __restrict__ P1,
                                                               const u32* __restrict__ total, size_t nC1,
                                                               u32* __restrict__ coarse) {
   extern __shared__ u32 sm[];
@@ -261,11 +299,12 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sort1_scatter(const uint16_t* __
 #pragma unroll
   for (int k = 0; k < PER; k++) {
     const int i = i0 + k * SORT_BLOCK + threadIdx.x;
-    const bool live = dreg[k] != 0;
-    const u32 hi = dreg[k] >> lo_bits;
+    u32 b, neg;
+    const bool live = digit_decode(dreg[k], sd, b, neg);
+    const u32 hi = b >> lo_bits;
     const u32 r = lds_rank(lcur, hi, live);
     if (live) {
-      stage[r] = ((u32)i << 8) | (dreg[k] & lo_mask);
+      stage[r] = ((u32)i << 8) | (neg << 7) | (b & lo_mask);
       dest[r] = r + gdelta[hi];
     }
   }
@@ -333,7 +372,8 @@ __device__ __forceinline__ bool sortbig_item(const BigBins* bb, u32 item, u32& r
 
 // T[item][lo] = count of lo in the item's chunk
 __global__ void __launch_bounds__(SORT_BLOCK) k_sortbig_count(const u32* __restrict__ coarse,
-                                                              const BigBins* __restrict__ bb, u32* __restrict__ T) {
+                                                              const BigBins* __restrict__ bb, u32 lo_mask,
+                                                              u32* __restrict__ T) {
   __shared__ u32 cnt[256];
   const u32 n_items = bb->n_items;
   for (u32 item = blockIdx.x; item < n_items; item += gridDim.x) {
@@ -347,7 +387,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sortbig_count(const u32* __restr
     for (u32 e = lo0 + threadIdx.x; e - threadIdx.x < hi0; e += SORT_BLOCK) {
       const bool live = e < hi0;
       const u32 v = live ? coarse[e] : 0u;
-      lds_rank(cnt, v & 0xffu, live);
+      lds_rank(cnt, v & lo_mask, live);
     }
     __syncthreads();
     T[(size_t)item * 256 + threadIdx.x] = cnt[threadIdx.x];
@@ -392,9 +432,10 @@ __global__ void __launch_bounds__(256) k_sortbig_scan(const BigBins* __restrict_
 __global__ void __launch_bounds__(SORT_BLOCK) k_sortbig_scatter(const u32* __restrict__ coarse,
                                                                 const BigBins* __restrict__ bb,
                                                                 const u32* __restrict__ T, int c, int lo_bits,
-                                                                int NH, u32* __restrict__ sidx,
+                                                                u32 sign_bit, int NH, u32* __restrict__ sidx,
                                                                 u32* __restrict__ sbid) {
   __shared__ u32 cur[256];
+  const u32 lo_mask = (1u << lo_bits) - 1u;
   const u32 n_items = bb->n_items;
   for (u32 item = blockIdx.x; item < n_items; item += gridDim.x) {
     u32 r, k;
@@ -410,10 +451,10 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sortbig_scatter(const u32* __res
     for (u32 e = lo0 + threadIdx.x; e - threadIdx.x < hi0; e += SORT_BLOCK) {
       const bool live = e < hi0;
       const u32 v = live ? coarse[e] : 0u;
-      const u32 lo = v & 0xffu;
+      const u32 lo = v & lo_mask;
       const u32 pos = lds_rank(cur, lo, live);
       if (live) {
-        sidx[pos] = v >> 8;
+        sidx[pos] = (v >> 8) | ((v & sign_bit) << 24);
         sbid[pos] = bucket0 + lo;
       }
     }
@@ -424,7 +465,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sortbig_scatter(const u32* __res
 // one block per coarse bin (w, h): finishes the sort inside the bin
 __global__ void __launch_bounds__(SORT_BLOCK) k_sort2(const u32* __restrict__ coarse, const u32* __restrict__ P1,
                                                       const u32* __restrict__ total, int c, int lo_bits, int NH,
-                                                      int nblk, int nbins, u32 big_thresh,
+                                                      u32 sign_bit, int nblk, int nbins, u32 big_thresh,
                                                       u32* __restrict__ hist, u32* __restrict__ sidx,
                                                       u32* __restrict__ sbid) {
   __shared__ u32 cnt[256];
@@ -432,6 +473,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sort2(const u32* __restrict__ co
   __shared__ u32 wsum[SORT_BLOCK / 64];
   const int bin = blockIdx.x;
   const int NLO = 1 << lo_bits;
+  const u32 lo_mask = (1u << lo_bits) - 1u;
   const u32 b0 = P1[(size_t)bin * nblk];
   const u32 b1 = (bin + 1 < nbins) ? P1[(size_t)(bin + 1) * nblk] : *total;
   const int w = bin / NH, h = bin - w * NH;
@@ -457,13 +499,13 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sort2(const u32* __restrict__ co
 #pragma unroll
     for (int k = 0; k < S2_PER; k++) {
       const u32 e = b0 + k * SORT_BLOCK + threadIdx.x;
-      lds_rank(cnt, vreg[k] & 0xffu, e < b1);
+      lds_rank(cnt, vreg[k] & lo_mask, e < b1);
     }
   } else {
     for (u32 e = b0 + threadIdx.x; e - threadIdx.x < b1; e += SORT_BLOCK) {  // uniform trip count
       const bool live = e < b1;
       const u32 v = live ? coarse[e] : 0u;
-      lds_rank(cnt, v & 0xffu, live);
+      lds_rank(cnt, v & lo_mask, live);
     }
   }
   __syncthreads();
@@ -492,7 +534,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sort2(const u32* __restrict__ co
     for (int k = 0; k < S2_PER; k++) {
       const u32 e = b0 + k * SORT_BLOCK + threadIdx.x;
       const bool live = e < b1;
-      const u32 lo = vreg[k] & 0xffu;
+      const u32 lo = vreg[k] & lo_mask;
       const u32 pos = lds_rank(cur, lo, live);
       if (live) stage[pos - b0] = vreg[k];
     }
@@ -500,17 +542,17 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sort2(const u32* __restrict__ co
     // sorted inside LDS; write out in order (coalesced)
     for (u32 j = threadIdx.x; j < b1 - b0; j += SORT_BLOCK) {
       const u32 v = stage[j];
-      sidx[b0 + j] = v >> 8;
-      sbid[b0 + j] = bucket0 + (v & 0xffu);
+      sidx[b0 + j] = (v >> 8) | ((v & sign_bit) << 24);
+      sbid[b0 + j] = bucket0 + (v & lo_mask);
     }
   } else {
     for (u32 e = b0 + threadIdx.x; e - threadIdx.x < b1; e += SORT_BLOCK) {
       const bool live = e < b1;
       const u32 v = live ? coarse[e] : 0u;
-      const u32 lo = v & 0xffu;
+      const u32 lo = v & lo_mask;
       const u32 pos = lds_rank(cur, lo, live);
       if (live) {
-        sidx[pos] = v >> 8;
+        sidx[pos] = (v >> 8) | ((v & sign_bit) << 24);
         sbid[pos] = bucket0 + lo;
       }
     }
@@ -609,12 +651,22 @@ struct RunAcc;
 template <class CV>
 struct RunAcc<CV, true> {
   using IO = CurveIO<CV>;
+  using EA = typename CV::EA;
   Xyzz<CV> a;
+  // sorted index entry: base index, bit 31 = subtract (negative signed digit): y -> -y, branch-free.
+  // -0 comes out as p, which is_zero() accepts, so the (0, 0) infinity marker survives.
+  static __device__ __forceinline__ Aff<EA> load_signed(const u32* pts, const u32* idx, long long p) {
+    const u32 v = idx[p];
+    Aff<EA> q = IO::load_aff(pts + (size_t)(v & ~SIDX_NEG) * IO::AFF_WORDS);
+    const EA ny = EA(reduce_to<17>(neg(q.y)));
+    q.y = select_el((v & SIDX_NEG) != 0, ny, q.y);
+    return q;
+  }
   __device__ __forceinline__ void start(const u32* pts, const u32* idx, long long p) {
-    a = xyzz_from_affine<CV>(IO::load_aff(pts + (size_t)idx[p] * IO::AFF_WORDS));
+    a = xyzz_from_affine<CV>(load_signed(pts, idx, p));
   }
   __device__ __forceinline__ void add(const u32* pts, const u32* idx, long long p) {
-    a = xyzz_madd(a, IO::load_aff(pts + (size_t)idx[p] * IO::AFF_WORDS));
+    a = xyzz_madd(a, load_signed(pts, idx, p));
   }
   __device__ __forceinline__ void store(u32* dst) const { IO::store_rec_xyzz(a, dst); }
 };
@@ -927,7 +979,7 @@ __device__ void write_normalised(const Jac<CV>& r, u32* out) {
 // kernel then loses 1 CU of 256 instead of 20 % of its time — experimental, see msm_var.hip.
 template <class CV, bool EXCLUSIVE>
 __global__ void __launch_bounds__(256) k_finalize(const u32* __restrict__ A_w, const u32* __restrict__ R_w, int m,
-                                                  int g, int W, int c, u32* __restrict__ out) {
+                                                  int g, int W, int c, int sd, u32* __restrict__ out) {
   using IO = CurveIO<CV>;
   __shared__ volatile int done;
   __shared__ u32 sw[64 * IO::JAC_WORDS];  // S_w of up to 64 windows at a time
@@ -944,7 +996,7 @@ __global__ void __launch_bounds__(256) k_finalize(const u32* __restrict__ A_w, c
   }
   __builtin_amdgcn_s_setprio(3);
   // The last window-sum level left m (<= a few) elements (A_j, R_j) per window:
-  //     S_w = sum_j A_j + 2^g * sum_j j * R_j
+  //     S_w = sum_j A_j + 2^g * sum_j j * R_j     (+ sum_j R_j with signed digits: bucket b weighs b + 1)
   // — lane w finishes window w (all windows in parallel), then lane 0 runs Horner over the S_w.
   const int l = threadIdx.x;
   Jac<CV> r = jac_infinity<CV>();
@@ -962,6 +1014,10 @@ __global__ void __launch_bounds__(256) k_finalize(const u32* __restrict__ A_w, c
       if (m > 1) {
         for (int k = 0; k < g; k++) acc = jac_dbl(acc);
         asum = jac_add(asum, acc);
+      }
+      if (sd) {
+        run = jac_add(run, IO::load_jac(R_w + (size_t)w * m * IO::JAC_WORDS));  // + R_0: all buckets
+        asum = jac_add(asum, run);
       }
       IO::store_jac(asum, sw + (size_t)l * IO::JAC_WORDS);
     }

@@ -41,6 +41,8 @@ static MsmPlan make_plan(int n) {
   if (c < 1) c = 1;
   if (c > 16) c = 16;
   p.c = c;
+  p.sd = p.glv && c >= 2 && env_int("OZK_MSM_SIGNED", 1) != 0;
+  p.cb = c - p.sd;
   p.W = ((p.glv ? 128 : 256) + c - 1) / c;
   p.L1 = env_int("OZK_MSM_L1", 32);
   p.LK = env_int("OZK_MSM_LK", 16);
@@ -88,9 +90,10 @@ static MsmLayout make_layout3(const MsmPlan& p, void* sorted, void* sort_ws, voi
   using IO = CurveIO<CV>;
   MsmLayout L;
   L.cap = (size_t)p.n * p.W;
-  L.NB = (size_t)p.W << p.c;
-  L.lo_bits = p.c < 8 ? p.c : 8;
-  L.NH = 1 << (p.c - L.lo_bits);
+  L.NB = (size_t)p.W << p.cb;
+  const int lo_max = p.sd ? 7 : 8;  // signed: bit 7 of the packed coarse word carries the sign
+  L.lo_bits = p.cb < lo_max ? p.cb : lo_max;
+  L.NH = 1 << (p.cb - L.lo_bits);
   L.nblk = (p.n + SORT_CHUNK - 1) / SORT_CHUNK;
   L.nC1 = (size_t)p.W * L.NH * L.nblk;
   Bump a(sorted, ~(size_t)0);
@@ -122,7 +125,7 @@ static MsmLayout make_layout3(const MsmPlan& p, void* sorted, void* sort_ws, voi
   L.slot_bid[1] = c.take<u32>(L.slots1);
   L.slot_pts[1] = c.take<u32>(L.slots1 * IO::REC_WORDS);
   c.take<u32>(64);
-  L.m1 = (((size_t)1 << p.c) + p.S - 1) / p.S;
+  L.m1 = (((size_t)1 << p.cb) + p.S - 1) / p.S;
   if (rb) {
     rb->sorted = (a.off + 255) & ~(size_t)255;
     rb->sort_ws = (b.off + 255) & ~(size_t)255;
@@ -147,8 +150,8 @@ template <class CV>
 static size_t tail_layout(const MsmPlan& p, MsmLayout& L, void* tail, size_t tail_bytes) {
   using IO = CurveIO<CV>;
   Bump b(tail, tail_bytes);
-  L.NB = (size_t)p.W << p.c;
-  L.m1 = (((size_t)1 << p.c) + p.S - 1) / p.S;
+  L.NB = (size_t)p.W << p.cb;
+  L.m1 = (((size_t)1 << p.cb) + p.S - 1) / p.S;
   L.buckets = b.take<u32>(L.NB * IO::REC_WORDS);
   L.hist_t = b.take<u32>(L.NB);
   for (int k = 0; k < 2; k++) {
@@ -171,7 +174,7 @@ static bool wsum0_in_tail() { return env_int("OZK_MSM_WSUM0_IN_TAIL", 1) != 0; }
 static bool wsum_fused() { return env_int("OZK_MSM_WSUM_FUSED", 1) != 0; }
 // elements per window the first level leaves, and the g (log2 of buckets per element) they carry
 static void first_level_shape(const MsmPlan& p, int* m_out, int* g_out) {
-  const int m_in = 1 << p.c;
+  const int m_in = 1 << p.cb;
   const int nseg = (m_in + p.S - 1) / p.S;
   const int sg = ilog2((uint32_t)p.S);
   if (wsum_fused()) {
@@ -185,7 +188,7 @@ static void first_level_shape(const MsmPlan& p, int* m_out, int* g_out) {
 template <class CV>
 static void launch_wsum0(const MsmPlan& p, const MsmLayout& L, hipStream_t st, int prio) {
   const int TB = 256;
-  const int m_in = 1 << p.c;
+  const int m_in = 1 << p.cb;
   int m_out, g;
   first_level_shape(p, &m_out, &g);
   const int tot = m_out * p.W;
@@ -201,7 +204,7 @@ static void launch_wsum0(const MsmPlan& p, const MsmLayout& L, hipStream_t st, i
 // leaves the "sorted set".
 template <class CV>
 static int var_msm_sort(const void* d_bases, const void* d_scalars, int n, void* sorted, size_t sorted_bytes,
-                        void* sort_ws, size_t sort_ws_bytes, hipStream_t st) {
+                        void* sort_ws, size_t sort_ws_bytes, hipStream_t st, hipEvent_t order_ev = nullptr) {
   const MsmPlan p = make_plan(n);
   RegionBytes rb;
   const MsmLayout L = make_layout3<CV>(p, sorted, sort_ws, nullptr, &rb);
@@ -215,8 +218,8 @@ static int var_msm_sort(const void* d_bases, const void* d_scalars, int n, void*
   n = p.n;  // from here on: the points the pipeline sorts (2 * n_in with GLV)
   OZK_HIP(hipMemsetAsync(L.total, 0, 4 * sizeof(u32), st));
   if (p.glv) {
-    hipLaunchKernelGGL(k_digits_glv, dim3((n_in + TB - 1) / TB), dim3(TB), 0, st, scalars, n_in, p.c, p.W, L.digits,
-                       L.neg_flags);
+    hipLaunchKernelGGL(k_digits_glv, dim3((n_in + TB - 1) / TB), dim3(TB), 0, st, scalars, n_in, p.c, p.W, p.sd,
+                       L.digits, L.neg_flags);
     hipLaunchKernelGGL((k_convert_bases<CV>), dim3((n_in + TB - 1) / TB), dim3(TB), 0, st, bases, L.aff, n_in,
                        (const uint8_t*)L.neg_flags);
   } else {
@@ -227,27 +230,33 @@ static int var_msm_sort(const void* d_bases, const void* d_scalars, int n, void*
   // two-level counting sort by (window, digit): per-block LDS counts of the hi part, one global
   // exclusive scan, coarse scatter, then one block per coarse bin finishes by the lo part
   const size_t lds1 = (size_t)L.NH * sizeof(u32);
-  hipLaunchKernelGGL(k_sort1_count, dim3(L.nblk, p.W), dim3(SORT_BLOCK), lds1, st, L.digits, n, L.lo_bits, L.NH,
-                     L.nblk, L.C1);
+  hipLaunchKernelGGL(k_sort1_count, dim3(L.nblk, p.W), dim3(SORT_BLOCK), lds1, st, L.digits, n, L.lo_bits, p.sd,
+                     L.NH, L.nblk, L.C1);
   const int items = SCAN_BLOCK * SCAN_ITEMS;
   const int nb = (int)((L.nC1 + items - 1) / items);
   hipLaunchKernelGGL(k_scan_blocksum, dim3(nb), dim3(SCAN_BLOCK), 0, st, L.C1, (int)L.nC1, L.blocksum);
   hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, L.blocksum, nb, L.total);
   hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_BLOCK), 0, st, L.C1, (int)L.nC1, L.blocksum, L.P1);
   const size_t lds_sc = ((size_t)2 * L.NH + 2 * SORT_CHUNK) * sizeof(u32);
-  hipLaunchKernelGGL(k_sort1_scatter, dim3(L.nblk, p.W), dim3(SORT_BLOCK), lds_sc, st, L.digits, n, L.lo_bits, L.NH,
-                     L.nblk, L.P1, L.total, L.nC1, L.coarse);
+  hipLaunchKernelGGL(k_sort1_scatter, dim3(L.nblk, p.W), dim3(SORT_BLOCK), lds_sc, st, L.digits, n, L.lo_bits,
+                     p.sd, L.NH, L.nblk, L.P1, L.total, L.nC1, L.coarse);
   const int nbins = p.W * L.NH;
+  const u32 sign_bit = p.sd ? 0x80u : 0u;
   const u32 big_thresh = (u32)(n / 64) > SORT_BIG ? (u32)(n / 64) : SORT_BIG;
-  hipLaunchKernelGGL(k_sort2, dim3(nbins), dim3(SORT_BLOCK), 0, st, L.coarse, L.P1, L.total, p.c, L.lo_bits, L.NH,
-                     L.nblk, nbins, big_thresh, L.hist, L.sidx, L.sbid);
+  hipLaunchKernelGGL(k_sort2, dim3(nbins), dim3(SORT_BLOCK), 0, st, L.coarse, L.P1, L.total, p.cb, L.lo_bits, L.NH,
+                     sign_bit, L.nblk, nbins, big_thresh, L.hist, L.sidx, L.sbid);
+  // Ordering hint for pipelined MSMs (see ozk_var_msm_tail_ordered_dev): everything up to here may
+  // overlap the previous MSM's window-sum levels; the bucket accumulation that follows fills every
+  // SIMD's register file, so the previous MSM's single-wave Horner kernel has to be resident first.
+  if (order_ev) OZK_HIP(hipStreamWaitEvent(st, order_ev, 0));
   // bins above the threshold (skewed digits), split over a fixed grid; no-ops otherwise
   hipLaunchKernelGGL(k_sortbig_list, dim3(1), dim3(256), 0, st, L.P1, L.total, L.nblk, nbins, big_thresh, L.bigbins);
-  hipLaunchKernelGGL(k_sortbig_count, dim3(1024), dim3(SORT_BLOCK), 0, st, L.coarse, L.bigbins, L.bigT);
-  hipLaunchKernelGGL(k_sortbig_scan, dim3(SORTBIG_MAXBINS), dim3(256), 0, st, L.bigbins, L.bigT, p.c, L.lo_bits, L.NH,
+  hipLaunchKernelGGL(k_sortbig_count, dim3(1024), dim3(SORT_BLOCK), 0, st, L.coarse, L.bigbins,
+                     (1u << L.lo_bits) - 1u, L.bigT);
+  hipLaunchKernelGGL(k_sortbig_scan, dim3(SORTBIG_MAXBINS), dim3(256), 0, st, L.bigbins, L.bigT, p.cb, L.lo_bits, L.NH,
                      L.hist);
-  hipLaunchKernelGGL(k_sortbig_scatter, dim3(1024), dim3(SORT_BLOCK), 0, st, L.coarse, L.bigbins, L.bigT, p.c,
-                     L.lo_bits, L.NH, L.sidx, L.sbid);
+  hipLaunchKernelGGL(k_sortbig_scatter, dim3(1024), dim3(SORT_BLOCK), 0, st, L.coarse, L.bigbins, L.bigT, p.cb,
+                     L.lo_bits, sign_bit, L.NH, L.sidx, L.sbid);
   OZK_HIP(hipGetLastError());
   return OZK_OK;
 }
@@ -303,13 +312,13 @@ static int var_msm_accum(int n, void* sorted, size_t sorted_bytes, void* accum_w
 // Head = SORT + ACCUMULATE on one stream, the three regions carved from one workspace.
 template <class CV>
 static int var_msm_head(const void* d_bases, const void* d_scalars, int n, void* ws, size_t ws_bytes, void* tail,
-                        size_t tail_bytes, hipStream_t st) {
+                        size_t tail_bytes, hipStream_t st, hipEvent_t order_ev = nullptr) {
   const RegionBytes rb = region_bytes<CV>(n);
   if (rb.sorted + rb.sort_ws + rb.accum_ws > ws_bytes)
     return fail(OZK_E_INVALID, "workspace too small: need %zu bytes, got %zu", rb.sorted + rb.sort_ws + rb.accum_ws,
                 ws_bytes);
   uint8_t* w = (uint8_t*)ws;
-  int rc = var_msm_sort<CV>(d_bases, d_scalars, n, w, rb.sorted, w + rb.sorted, rb.sort_ws, st);
+  int rc = var_msm_sort<CV>(d_bases, d_scalars, n, w, rb.sorted, w + rb.sorted, rb.sort_ws, st, order_ev);
   if (rc) return rc;
   return var_msm_accum<CV>(n, w, rb.sorted, w + rb.sorted + rb.sort_ws, rb.accum_ws, tail, tail_bytes, st);
 }
@@ -317,11 +326,12 @@ static int var_msm_head(const void* d_bases, const void* d_scalars, int n, void*
 // Tail phase: the latency-bound remainder (wave-cooperative window-sum levels, Horner over the
 // windows, affine normalisation).  Reads only the tail buffers; writes the wire-out result.
 template <class CV>
-static int var_msm_tail(int n, void* tail, size_t tail_bytes, void* d_out, hipStream_t st) {
+static int var_msm_tail(int n, void* tail, size_t tail_bytes, void* d_out, hipStream_t st,
+                        hipEvent_t order_ev = nullptr) {
   using CT = CV;
   const MsmPlan p = make_plan(n);
   MsmLayout L;
-  L.m1 = (((size_t)1 << p.c) + p.S - 1) / p.S;
+  L.m1 = (((size_t)1 << p.cb) + p.S - 1) / p.S;
   const size_t tneed = tail_layout<CV>(p, L, tail, tail_bytes);
   if (tneed > tail_bytes) return fail(OZK_E_INVALID, "tail buffer too small: need %zu bytes, got %zu", tneed, tail_bytes);
   if (wsum0_in_tail()) launch_wsum0<CV>(p, L, st, env_int("OZK_MSM_WSUM0_PRIO", 0));
@@ -356,17 +366,18 @@ static int var_msm_tail(int n, void* tail, size_t tail_bytes, void* d_out, hipSt
     g += 6;
     k ^= 1;
   }
-  // EXPERIMENTAL (off): with OZK_FINALIZE_EXCLUSIVE=1 the Horner kernel declares the whole register
-  // file of a CU so that no bucket-accumulation wave shares its SIMDs: +9 % pipelined throughput
-  // (362 -> 395 Mscalar-mul/s), but the process aborted reproducibly when ~60 HIP streams had been
-  // created and destroyed before it (suspected: mid-wave preemption of 512-register waves under
-  // queue oversubscription), so it is not the default.
+  if (order_ev) OZK_HIP(hipEventRecord(order_ev, st));  // the multi-wave levels are done
+  // One wave (Horner is serial).  EXPERIMENTAL (off): with OZK_FINALIZE_EXCLUSIVE=1 the kernel runs four
+  // waves that declare the whole register file of a CU so that no bucket-accumulation wave shares its
+  // SIMDs: +9 % pipelined throughput when measured, but the process aborted reproducibly when ~60 HIP
+  // streams had been created and destroyed before it (suspected: mid-wave preemption of 512-register
+  // waves under queue oversubscription), so it is not the default.
   if (env_int("OZK_FINALIZE_EXCLUSIVE", 0))
     hipLaunchKernelGGL((k_finalize<CT, true>), dim3(1), dim3(256), 0, st, L.wA[k], L.wR[k], m_in, g, p.W, p.c,
-                       (u32*)d_out);
+                       p.sd, (u32*)d_out);
   else
-    hipLaunchKernelGGL((k_finalize<CT, false>), dim3(1), dim3(256), 0, st, L.wA[k], L.wR[k], m_in, g, p.W, p.c,
-                       (u32*)d_out);
+    hipLaunchKernelGGL((k_finalize<CT, false>), dim3(1), dim3(64), 0, st, L.wA[k], L.wR[k], m_in, g, p.W, p.c,
+                       p.sd, (u32*)d_out);
   OZK_HIP(hipGetLastError());
   return OZK_OK;
 }
@@ -375,7 +386,7 @@ template <class CV>
 static size_t var_msm_tail_bytes(int n) {
   const MsmPlan p = make_plan(n);
   MsmLayout L;
-  L.m1 = (((size_t)1 << p.c) + p.S - 1) / p.S;
+  L.m1 = (((size_t)1 << p.cb) + p.S - 1) / p.S;
   return tail_layout<CV>(p, L, nullptr, 0);
 }
 
@@ -488,6 +499,36 @@ int ozk_var_msm_head_dev(const void* d_bases, const void* d_scalars, int32_t n, 
                                (hipStream_t)stream);
   return var_msm_head<G2Cfg>(d_bases, d_scalars, n, d_workspace, workspace_bytes, d_tail, tail_bytes,
                              (hipStream_t)stream);
+}
+int ozk_order_event_create(void** ev) {
+  if (!ev) return fail(OZK_E_INVALID, "null pointer argument");
+  hipEvent_t e = nullptr;
+  OZK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  *ev = (void*)e;
+  return OZK_OK;
+}
+int ozk_order_event_destroy(void* ev) {
+  if (ev) OZK_HIP(hipEventDestroy((hipEvent_t)ev));
+  return OZK_OK;
+}
+int ozk_var_msm_head_ordered_dev(const void* d_bases, const void* d_scalars, int32_t n, int32_t type,
+                                 void* d_workspace, size_t workspace_bytes, void* d_tail, size_t tail_bytes,
+                                 void* stream, void* previous_levels_done) {
+  if (!d_bases || !d_scalars || !d_workspace || !d_tail) return fail(OZK_E_INVALID, "null pointer argument");
+  if (n <= 0 || n > (1 << 24)) return fail(OZK_E_INVALID, "batch_size %d out of range [1, 2^24]", n);
+  if (type == OZK_G1)
+    return var_msm_head<G1Cfg>(d_bases, d_scalars, n, d_workspace, workspace_bytes, d_tail, tail_bytes,
+                               (hipStream_t)stream, (hipEvent_t)previous_levels_done);
+  return var_msm_head<G2Cfg>(d_bases, d_scalars, n, d_workspace, workspace_bytes, d_tail, tail_bytes,
+                             (hipStream_t)stream, (hipEvent_t)previous_levels_done);
+}
+int ozk_var_msm_tail_ordered_dev(int32_t n, int32_t type, void* d_tail, size_t tail_bytes, void* d_out, void* stream,
+                                 void* levels_done) {
+  if (!d_tail || !d_out) return fail(OZK_E_INVALID, "null pointer argument");
+  if (n <= 0 || n > (1 << 24)) return fail(OZK_E_INVALID, "batch_size %d out of range [1, 2^24]", n);
+  if (type == OZK_G1)
+    return var_msm_tail<G1Cfg>(n, d_tail, tail_bytes, d_out, (hipStream_t)stream, (hipEvent_t)levels_done);
+  return var_msm_tail<G2Cfg>(n, d_tail, tail_bytes, d_out, (hipStream_t)stream, (hipEvent_t)levels_done);
 }
 int ozk_var_msm_stage_bytes(int32_t n, int32_t type, size_t* sorted_bytes, size_t* sort_ws_bytes,
                             size_t* accum_ws_bytes) {

@@ -1,5 +1,7 @@
 """Device-resident entry points on torch CUDA(HIP) tensors: torch is plumbing only (HBM
 buffers, streams, torch.distributed); all arithmetic is in libozk_hip.so."""
+import ctypes
+
 import torch
 
 from . import lib as _lib
@@ -61,7 +63,23 @@ class VarMsmPipeline:
         self.side = torch.cuda.Stream(device=device)
         self.head_done = [torch.cuda.Event() for _ in range(depth)]
         self.tail_done = [torch.cuda.Event() for _ in range(depth)]
+        # ordering hint (include/ozk.h): the next head's bucket accumulation is dispatched after the
+        # previous tail's multi-wave levels, so that its single-wave Horner kernel is resident first
+        self.levels_done = []
+        for _ in range(depth):
+            ev = ctypes.c_void_p()
+            _lib.check(L.ozk_order_event_create(ctypes.byref(ev)))
+            self.levels_done.append(ev)
         self.count = 0
+
+    def __del__(self):
+        try:
+            L = _lib.load()
+            torch.cuda.synchronize()
+            for ev in self.levels_done:
+                L.ozk_order_event_destroy(ev)
+        except Exception:
+            pass
 
     def submit(self, d_bases, d_scalars):
         L = _lib.load()
@@ -69,13 +87,15 @@ class VarMsmPipeline:
         main = torch.cuda.current_stream()
         if self.count >= self.depth:
             main.wait_event(self.tail_done[slot])      # the tail that last used this slot's buffers
-        _lib.check(L.ozk_var_msm_head_dev(_ptr(d_bases), _ptr(d_scalars), self.n, self.type, _ptr(self.ws),
-                                          self.ws_bytes, _ptr(self.tails[slot]), self.tail_bytes,
-                                          int(main.cuda_stream)))
+        prev = self.levels_done[(self.count - 1) % self.depth] if (self.count and self.depth > 1) else None
+        _lib.check(L.ozk_var_msm_head_ordered_dev(_ptr(d_bases), _ptr(d_scalars), self.n, self.type, _ptr(self.ws),
+                                                  self.ws_bytes, _ptr(self.tails[slot]), self.tail_bytes,
+                                                  int(main.cuda_stream), prev))
         self.head_done[slot].record(main)
         self.side.wait_event(self.head_done[slot])
-        _lib.check(L.ozk_var_msm_tail_dev(self.n, self.type, _ptr(self.tails[slot]), self.tail_bytes,
-                                          _ptr(self.outs[slot]), int(self.side.cuda_stream)))
+        _lib.check(L.ozk_var_msm_tail_ordered_dev(self.n, self.type, _ptr(self.tails[slot]), self.tail_bytes,
+                                                  _ptr(self.outs[slot]), int(self.side.cuda_stream),
+                                                  self.levels_done[slot]))
         self.tail_done[slot].record(self.side)
         self.count += 1
         return self.count - 1
