@@ -44,7 +44,7 @@ static MsmPlan make_plan(int n) {
   p.sd = p.glv && c >= 2 && env_int("OZK_MSM_SIGNED", 1) != 0;
   p.cb = c - p.sd;
   p.W = ((p.glv ? 128 : 256) + c - 1) / c;
-  p.L1 = env_int("OZK_MSM_L1", 32);
+  p.L1 = env_int("OZK_MSM_L1", 40);
   p.LK = env_int("OZK_MSM_LK", 16);
   if (p.L1 < 2) p.L1 = 2;
   if (p.LK < 4) p.LK = 4;
