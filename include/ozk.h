@@ -169,6 +169,22 @@ size_t ozk_fft_workspace_bytes(int32_t n);
 int ozk_fft_dev(const void* d_in, int32_t n, const uint8_t* omega_host32, void* d_out,
                 void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------- QAP witness map (the FFT path's caller) -------------
+ * What R1CStoQAP.R1CStoQAPWitness (reductions/r1cs_to_qap/R1CStoQAP.java:163-230) does between the
+ * constraint evaluations and the H query of the prover: 3 inverse FFTs, 3 coset FFTs, (A o B - C) / Z on
+ * the coset (SerialFFT.java:86-115,158-163; FFTAuxiliary.multiplyByCoset :224-232), 1 coset inverse FFT,
+ * one trailing zero — seven transforms and the pointwise stages without leaving HBM.  There is no JNI
+ * native for it in the reference (Java loops over List<Fp>); INTEGRATION.md shows the optional binding.
+ * A, B, C: m x 32 B LE (evaluations on the domain S, m a power of two >= 2); omega: the domain's root of
+ * unity (SerialFFT.java:24-28), g: the coset shift (Fp.multiplicativeGenerator), 32 B LE each;
+ * H: (m + 1) x 32 B LE coefficients (canonical).  */
+int ozk_qap_witness_host(const uint8_t* A, const uint8_t* B, const uint8_t* C, int32_t m, const uint8_t* omega,
+                         const uint8_t* g, int32_t task_id, uint8_t* H);
+size_t ozk_qap_witness_workspace_bytes(int32_t m);
+int ozk_qap_witness_dev(const void* d_A, const void* d_B, const void* d_C, int32_t m, const uint8_t* omega_host32,
+                        const uint8_t* g_host32, void* d_H, void* d_workspace, size_t workspace_bytes,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -346,6 +346,16 @@ JNIEXPORT jbyteArray JNICALL Java_algebra_msm_FixedBaseMSM_fieldBatchMSMNativeHe
 JNIEXPORT jbyteArray JNICALL Java_algebra_fft_FFTAuxiliary_serialRadix2FFTNativeHelper(
     JNIEnv* env, jclass cls, jobject inputs, jbyteArray omega, jint taskID);
 
+
+/* ---- OPTIONAL natives (not declared by the reference's Java; INTEGRATION.md §5 shows the two-line
+ * Java change that uses them) -------------------------------------------------------------------- */
+/* ([B[B[BI[B[BI)[B — the QAP witness map of R1CStoQAP.R1CStoQAPWitness (R1CStoQAP.java:163-230):
+ * evaluations A, B, C (m x 32 B LE each, flat), m, omega, g (<= 32 B LE), taskID -> (m + 1) x 32 B LE
+ * coefficients of H.  ozk_qap_witness_host. */
+JNIEXPORT jbyteArray JNICALL Java_algebra_fft_FFTAuxiliary_qapWitnessNativeHelper(
+    JNIEnv* env, jclass cls, jbyteArray a, jbyteArray b, jbyteArray c, jint m, jbyteArray omega, jbyteArray g,
+    jint taskID);
+
 #ifdef __cplusplus
 }
 #endif

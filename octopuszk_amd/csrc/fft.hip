@@ -66,7 +66,8 @@ __global__ void __launch_bounds__(256) k_tw_full(const u32* __restrict__ small, 
 // ---- one pass of K stages over an LDS tile ---------------------------------
 struct PassArgs {
   const u32* in;    // FIRST: wire input (n x 8 words, plain canonical); else packed workspace
-  u32* out;         // LAST: wire out (n x 16 words LE); else packed workspace (n x 8 words)
+  u32* out;         // LAST: wire out (n x out_stride words LE); else packed workspace (n x 8 words)
+  int out_stride;   // 16: the JNI's 64-byte elements (upper half zero); 8: compact 32-byte elements
   const u32* tw;    // omega^t, t < n/2, Montgomery, packed
   int n, logn;
   int sbits;        // stages already done = log2 of the butterfly distance entering this pass
@@ -129,11 +130,13 @@ __device__ __forceinline__ void fft_store_tile(u32* lds, const PassArgs& a, int 
     u32 o[8];
     if (last) {
       pack(canonical(v), o);
-      uint4* dst = reinterpret_cast<uint4*>(a.out + (size_t)i * 16);
+      uint4* dst = reinterpret_cast<uint4*>(a.out + (size_t)i * a.out_stride);
       dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
       dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
-      dst[2] = make_uint4(0, 0, 0, 0);
-      dst[3] = make_uint4(0, 0, 0, 0);
+      if (a.out_stride == 16) {
+        dst[2] = make_uint4(0, 0, 0, 0);
+        dst[3] = make_uint4(0, 0, 0, 0);
+      }
     } else {
       pack(reduce_to<64>(v), o);
       uint4* dst = reinterpret_cast<uint4*>(a.out + (size_t)i * 8);
@@ -175,7 +178,7 @@ __global__ void __launch_bounds__(FFT_THREADS) k_fft_pass(PassArgs a, int last) 
 // algorithm (bit reversal + stages), one butterfly per lane per stage.
 __global__ void __launch_bounds__(FFT_THREADS) k_fft_small(const u32* __restrict__ in, u32* __restrict__ out,
                                                            const u32* __restrict__ tw, int n, int logn,
-                                                           u32* __restrict__ scratch) {
+                                                           u32* __restrict__ scratch, int out_stride) {
   using ET = ElemTraits<Fe<FrP, 32>>;
   for (int i = threadIdx.x; i < n; i += FFT_THREADS) {
     const int src = logn ? (int)(__brev((unsigned)i) >> (32 - logn)) : 0;
@@ -211,9 +214,8 @@ __global__ void __launch_bounds__(FFT_THREADS) k_fft_small(const u32* __restrict
     u32 o[8];
     pack(canonical(ET::load(scratch + (size_t)i * 8)), o);
 #pragma unroll
-    for (int k = 0; k < 8; k++) out[(size_t)i * 16 + k] = o[k];
-#pragma unroll
-    for (int k = 8; k < 16; k++) out[(size_t)i * 16 + k] = 0;
+    for (int k = 0; k < 8; k++) out[(size_t)i * out_stride + k] = o[k];
+    for (int k = 8; k < out_stride; k++) out[(size_t)i * out_stride + k] = 0;
   }
 }
 
@@ -238,24 +240,29 @@ static FftLayout fft_layout(int n, void* wsp, size_t wsb) {
   return L;
 }
 
-static int fft_dev(const void* d_in, int n, const uint8_t* omega_host, void* d_out, void* wsp, size_t wsb,
-                   hipStream_t st) {
-  const int logn = ilog2((uint32_t)n);
-  const FftLayout L = fft_layout(n, wsp, wsb);
-  if (L.bytes > wsb) return fail(OZK_E_INVALID, "workspace too small: need %zu bytes, got %zu", L.bytes, wsb);
-  OZK_HIP(hipMemcpyAsync(L.omega, omega_host, 32, hipMemcpyHostToDevice, st));
+// omega (device, wire form) -> tw[t] = omega^t, t < n/2 (scratch: small, (lo + hi) x 8 words)
+static void fft_build_twiddles(const u32* d_omega, int n, u32* small, u32* tw, hipStream_t st) {
   const int half = n / 2 > 0 ? n / 2 : 1;
-  hipLaunchKernelGGL(k_tw_small, dim3((L.lo + L.hi + 255) / 256), dim3(256), 0, st, L.omega, L.lo, L.hi, L.small);
-  hipLaunchKernelGGL(k_tw_full, dim3((half + 255) / 256), dim3(256), 0, st, L.small, L.lo, half, L.tw);
+  const int lo = half < TW_LO ? half : TW_LO;
+  const int hi = (half + lo - 1) / lo;
+  hipLaunchKernelGGL(k_tw_small, dim3((lo + hi + 255) / 256), dim3(256), 0, st, d_omega, lo, hi, small);
+  hipLaunchKernelGGL(k_tw_full, dim3((half + 255) / 256), dim3(256), 0, st, small, lo, half, tw);
+}
+
+// the transform proper: d_in (n x 8 words) -> d_out (n x out_stride words), in place allowed only
+// through the two ping-pong buffers (d_out may be one of them only if it is not read by the last pass)
+static int fft_core(const u32* d_in, int n, const u32* tw, u32* d_out, int out_stride, u32* buf0, u32* buf1,
+                    hipStream_t st) {
+  const int logn = ilog2((uint32_t)n);
   if (n < FFT_TILE) {
-    hipLaunchKernelGGL(k_fft_small, dim3(1), dim3(FFT_THREADS), 0, st, (const u32*)d_in, (u32*)d_out, L.tw, n, logn,
-                       L.buf[0]);
+    hipLaunchKernelGGL(k_fft_small, dim3(1), dim3(FFT_THREADS), 0, st, d_in, d_out, tw, n, logn, buf0, out_stride);
     OZK_HIP(hipGetLastError());
     return OZK_OK;
   }
   // passes of up to FFT_MAXK stages; the tile needs 2^K <= FFT_TILE
   int sbits = 0, cur = 0;
-  const u32* src = (const u32*)d_in;
+  u32* bufs[2] = {buf0, buf1};
+  const u32* src = d_in;
   bool first = true;
   while (sbits < logn) {
     int K = logn - sbits;
@@ -263,8 +270,9 @@ static int fft_dev(const void* d_in, int n, const uint8_t* omega_host, void* d_o
     const bool last = sbits + K == logn;
     PassArgs a;
     a.in = src;
-    a.out = last ? (u32*)d_out : L.buf[cur];
-    a.tw = L.tw;
+    a.out = last ? d_out : bufs[cur];
+    a.out_stride = out_stride;
+    a.tw = tw;
     a.n = n;
     a.logn = logn;
     a.sbits = sbits;
@@ -280,6 +288,176 @@ static int fft_dev(const void* d_in, int n, const uint8_t* omega_host, void* d_o
     sbits += K;
     first = false;
   }
+  OZK_HIP(hipGetLastError());
+  return OZK_OK;
+}
+
+static int fft_dev(const void* d_in, int n, const uint8_t* omega_host, void* d_out, void* wsp, size_t wsb,
+                   hipStream_t st) {
+  const FftLayout L = fft_layout(n, wsp, wsb);
+  if (L.bytes > wsb) return fail(OZK_E_INVALID, "workspace too small: need %zu bytes, got %zu", L.bytes, wsb);
+  OZK_HIP(hipMemcpyAsync(L.omega, omega_host, 32, hipMemcpyHostToDevice, st));
+  fft_build_twiddles(L.omega, n, L.small, L.tw, st);
+  return fft_core((const u32*)d_in, n, L.tw, (u32*)d_out, 16, L.buf[0], L.buf[1], st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// QAP witness map: the caller of the FFT path.
+// R1CStoQAP.R1CStoQAPWitness (reductions/r1cs_to_qap/R1CStoQAP.java:163-230) from the evaluations
+// of A, B, C on the domain S (m = |S| a power of two) to the m + 1 coefficients of H:
+//     a = iFFT_S(A), b = iFFT_S(B), c = iFFT_S(C)                 SerialFFT.radix2InverseFFT  (:86-95)
+//     A' = FFT_S(a_i g^i), B', C' likewise                        radix2CosetFFT (:100-105), multiplyByCoset
+//                                                                 (FFTAuxiliary.java:224-232)
+//     H_T = (A' o B' - C') / Z(g),  Z(g) = g^m - 1                divideByZOnCoset (SerialFFT.java:158-163)
+//     h = iFFT_S(H_T) o g^-i ; h_m = 0                            radix2CosetInverseFFT (:111-115), :225
+// Seven transforms over two twiddle tables (omega, omega^-1) built once, and four streaming pointwise
+// kernels that fold the 1/m of the inverse transforms into the coset powers; data never leaves HBM and
+// stays in plain (non-Montgomery) form — constants and power tables are in Montgomery form, so every
+// pointwise product is one multiplication.
+struct QapConsts {  // device-resident, packed 8 words each
+  u32 omega[8], omega_inv[8], g[8], g_inv[8];  // wire form (plain canonical)
+  u32 m_inv_mont[8];                           // (1/m) R
+  u32 zinv_mont[8];                            // (1 / (g^m - 1)) R
+};
+
+// omega^-1 = omega^(m-1), g^-1, 1/m, 1/Z(g): one block (one lane) each, side by side — every one is
+// a ~0.25 ms serial exponentiation / Fermat inversion
+__global__ void k_qap_consts(QapConsts* __restrict__ c, int m) {
+  if (threadIdx.x != 0) return;
+  u32 w[8], o[8];
+  if (blockIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = c->omega[i];
+    const Fe<FrP, 32> om = Fe<FrP, 32>(to_mont<FrP>(w));
+    Fe<FrP, 32> oi = fe_one<FrP>();
+    const unsigned e1 = (unsigned)(m - 1);
+    for (int b = 31; b >= 0; b--) {
+      oi = Fe<FrP, 32>(sqr(oi));
+      if ((e1 >> b) & 1) oi = Fe<FrP, 32>(mul(oi, om));
+    }
+    from_mont(oi, o);
+#pragma unroll
+    for (int i = 0; i < 8; i++) c->omega_inv[i] = o[i];
+  } else if (blockIdx.x == 1) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = c->g[i];
+    from_mont(inv(to_mont<FrP>(w)), o);
+#pragma unroll
+    for (int i = 0; i < 8; i++) c->g_inv[i] = o[i];
+  } else if (blockIdx.x == 2) {
+    u32 mw[8] = {(u32)m, 0, 0, 0, 0, 0, 0, 0};
+    pack(canonical(inv(to_mont<FrP>(mw))), o);
+#pragma unroll
+    for (int i = 0; i < 8; i++) c->m_inv_mont[i] = o[i];
+  } else if (blockIdx.x == 3) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = c->g[i];
+    const Fe<FrP, 32> g = Fe<FrP, 32>(to_mont<FrP>(w));
+    Fe<FrP, 32> gm = fe_one<FrP>();
+    const unsigned e2 = (unsigned)m;
+    for (int b = 31; b >= 0; b--) {
+      gm = Fe<FrP, 32>(sqr(gm));
+      if ((e2 >> b) & 1) gm = Fe<FrP, 32>(mul(gm, g));
+    }
+    pack(canonical(inv(sub(gm, fe_one<FrP>()))), o);  // Z(g) != 0: g generates Fr*, m < r - 1
+#pragma unroll
+    for (int i = 0; i < 8; i++) c->zinv_mont[i] = o[i];
+  }
+}
+
+// data[i] <- data[i] * base^i * k   (pw: two-level power table of base as built by k_tw_small with
+// lo = TW_LO: pw[j] = base^j, pw[lo + j] = base^(j lo); k in Montgomery form).  base^0 = 1 leaves
+// element 0 multiplied by k only, as multiplyByCoset does (FFTAuxiliary.java:227-231).
+__global__ void __launch_bounds__(256) k_coset_scale(u32* __restrict__ data, int n, int stride,
+                                                     const u32* __restrict__ pw, int lo,
+                                                     const u32* __restrict__ k_mont) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  using ET = ElemTraits<Fe<FrP, 16>>;
+  const uint4* sp = reinterpret_cast<const uint4*>(data + (size_t)i * stride);
+  const uint4 v0 = sp[0], v1 = sp[1];
+  const u32 w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+  const auto x = unpack<FrP, 85>(w);
+  const auto p = mul(ET::load(pw + (size_t)(i % lo) * 8), ET::load(pw + (size_t)(lo + i / lo) * 8));  // base^i R
+  // x p / R = x base^i (plain); then times k: mul(., kR) keeps it plain
+  u32 o[8];
+  pack(canonical(mul(mul(x, p), ET::load(k_mont))), o);
+  uint4* dst = reinterpret_cast<uint4*>(data + (size_t)i * stride);
+  dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+  dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+}
+
+// h[i] <- (a[i] b[i] - c[i]) zinv   (all plain; zinv, R^2 in Montgomery / raw form)
+__global__ void __launch_bounds__(256) k_qap_pointwise(const u32* a, const u32* __restrict__ b,
+                                                       const u32* __restrict__ c, int n,
+                                                       const u32* __restrict__ zinv_mont, u32* h) {  // h may be a
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  using ET = ElemTraits<Fe<FrP, 16>>;
+  const auto x = ET::load(a + (size_t)i * 8), y = ET::load(b + (size_t)i * 8), z = ET::load(c + (size_t)i * 8);
+  const auto r2 = fe_const<FrP, 16>(FrP::R2);
+  const auto xy = mul(mul(x, y), r2);          // x y (plain)
+  u32 o[8];
+  pack(canonical(mul(sub(xy, z), ET::load(zinv_mont))), o);
+  uint4* dst = reinterpret_cast<uint4*>(h + (size_t)i * 8);
+  dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+  dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+}
+
+struct QapLayout {
+  QapConsts* consts;
+  u32 *small, *tw_f, *tw_i, *pw_g, *pw_gi, *buf[2], *va, *vb, *vc;
+  size_t bytes;
+  int lo;
+};
+static QapLayout qap_layout(int m, void* wsp, size_t wsb) {
+  QapLayout L;
+  Bump b(wsp, wsb);
+  const int half = m / 2 > 0 ? m / 2 : 1;
+  L.lo = TW_LO;
+  const int hi = (m + TW_LO - 1) / TW_LO + 1;
+  L.consts = b.take<QapConsts>(1);
+  L.small = b.take<u32>((size_t)(TW_LO + hi) * 8);
+  L.tw_f = b.take<u32>((size_t)half * 8);
+  L.tw_i = b.take<u32>((size_t)half * 8);
+  L.pw_g = b.take<u32>((size_t)(TW_LO + hi) * 8);
+  L.pw_gi = b.take<u32>((size_t)(TW_LO + hi) * 8);
+  L.buf[0] = b.take<u32>((size_t)m * 8);
+  L.buf[1] = b.take<u32>((size_t)m * 8);
+  L.va = b.take<u32>((size_t)m * 8);
+  L.vb = b.take<u32>((size_t)m * 8);
+  L.vc = b.take<u32>((size_t)m * 8);
+  b.take<u32>(64);
+  L.bytes = b.off;
+  return L;
+}
+
+static int qap_witness_dev(const void* d_A, const void* d_B, const void* d_C, int m, const uint8_t* omega_host,
+                           const uint8_t* g_host, void* d_H, void* wsp, size_t wsb, hipStream_t st) {
+  const QapLayout L = qap_layout(m, wsp, wsb);
+  if (L.bytes > wsb) return fail(OZK_E_INVALID, "workspace too small: need %zu bytes, got %zu", L.bytes, wsb);
+  OZK_HIP(hipMemcpyAsync(L.consts->omega, omega_host, 32, hipMemcpyHostToDevice, st));
+  OZK_HIP(hipMemcpyAsync(L.consts->g, g_host, 32, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_qap_consts, dim3(4), dim3(64), 0, st, L.consts, m);
+  fft_build_twiddles(L.consts->omega, m, L.small, L.tw_f, st);
+  fft_build_twiddles(L.consts->omega_inv, m, L.small, L.tw_i, st);
+  const int hi = (m + TW_LO - 1) / TW_LO + 1;
+  hipLaunchKernelGGL(k_tw_small, dim3((TW_LO + hi + 255) / 256), dim3(256), 0, st, L.consts->g, TW_LO, hi, L.pw_g);
+  hipLaunchKernelGGL(k_tw_small, dim3((TW_LO + hi + 255) / 256), dim3(256), 0, st, L.consts->g_inv, TW_LO, hi, L.pw_gi);
+  const int TB = 256, nb = (m + TB - 1) / TB;
+  const u32* in[3] = {(const u32*)d_A, (const u32*)d_B, (const u32*)d_C};
+  u32* v[3] = {L.va, L.vb, L.vc};
+  int rc;
+  for (int k = 0; k < 3; k++) {
+    // coefficients (times m), then a_i g^i / m, then the evaluations on the coset
+    if ((rc = fft_core(in[k], m, L.tw_i, v[k], 8, L.buf[0], L.buf[1], st))) return rc;
+    hipLaunchKernelGGL(k_coset_scale, dim3(nb), dim3(TB), 0, st, v[k], m, 8, L.pw_g, TW_LO, L.consts->m_inv_mont);
+    if ((rc = fft_core(v[k], m, L.tw_f, v[k], 8, L.buf[0], L.buf[1], st))) return rc;
+  }
+  hipLaunchKernelGGL(k_qap_pointwise, dim3(nb), dim3(TB), 0, st, L.va, L.vb, L.vc, m, L.consts->zinv_mont, L.va);
+  if ((rc = fft_core(L.va, m, L.tw_i, (u32*)d_H, 8, L.buf[0], L.buf[1], st))) return rc;
+  hipLaunchKernelGGL(k_coset_scale, dim3(nb), dim3(TB), 0, st, (u32*)d_H, m, 8, L.pw_gi, TW_LO, L.consts->m_inv_mont);
+  OZK_HIP(hipMemsetAsync((u32*)d_H + (size_t)m * 8, 0, 32, st));  // coefficientsH.add(zero), R1CStoQAP.java:225
   OZK_HIP(hipGetLastError());
   return OZK_OK;
 }
@@ -301,6 +479,58 @@ int ozk_fft_dev(const void* d_in, int32_t n, const uint8_t* omega_host32, void* 
   if (n <= 0 || (n & (n - 1)) || n > (1 << 28))
     return fail(OZK_E_INVALID, "FFT size %d is not a power of two in [1, 2^28]", n);
   return fft_dev(d_in, n, omega_host32, d_out, d_workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+size_t ozk_qap_witness_workspace_bytes(int32_t m) {
+  if (m <= 1 || (m & (m - 1))) return 0;
+  return qap_layout(m, nullptr, 0).bytes;
+}
+
+int ozk_qap_witness_dev(const void* d_A, const void* d_B, const void* d_C, int32_t m, const uint8_t* omega_host32,
+                        const uint8_t* g_host32, void* d_H, void* d_workspace, size_t workspace_bytes,
+                        void* stream) {
+  if (!d_A || !d_B || !d_C || !omega_host32 || !g_host32 || !d_H || !d_workspace)
+    return fail(OZK_E_INVALID, "null pointer argument");
+  if (m <= 1 || (m & (m - 1)) || m > (1 << 28))
+    return fail(OZK_E_INVALID, "domain size %d is not a power of two in [2, 2^28]", m);
+  return qap_witness_dev(d_A, d_B, d_C, m, omega_host32, g_host32, d_H, d_workspace, workspace_bytes,
+                         (hipStream_t)stream);
+}
+
+int ozk_qap_witness_host(const uint8_t* A, const uint8_t* B, const uint8_t* C, int32_t m, const uint8_t* omega,
+                         const uint8_t* g, int32_t task_id, uint8_t* H) {
+  if (!A || !B || !C || !omega || !g || !H) return fail(OZK_E_INVALID, "null pointer argument");
+  if (m <= 1 || (m & (m - 1)) || m > (1 << 28))
+    return fail(OZK_E_INVALID, "domain size %d is not a power of two in [2, 2^28]", m);
+  int rc = select_device(task_id);
+  if (rc) return rc;
+  const size_t vb = (size_t)m * 32, hb = ((size_t)m + 1) * 32;
+  const size_t vpad = (vb + 255) & ~(size_t)255, hpad = (hb + 255) & ~(size_t)255;
+  const size_t wsb = ozk_qap_witness_workspace_bytes(m);
+  uint8_t* d = nullptr;
+  hipStream_t st = nullptr;
+  OZK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  hipError_t e = hipMalloc((void**)&d, 3 * vpad + hpad + wsb + 1024);
+  if (e != hipSuccess) {
+    hipStreamDestroy(st);
+    return fail(OZK_E_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
+  }
+  uint8_t *dA = d, *dB = d + vpad, *dC = d + 2 * vpad, *dH = d + 3 * vpad, *dW = d + 3 * vpad + hpad;
+  rc = OZK_OK;
+  do {
+    if ((e = hipMemcpyAsync(dA, A, vb, hipMemcpyHostToDevice, st)) != hipSuccess) break;
+    if ((e = hipMemcpyAsync(dB, B, vb, hipMemcpyHostToDevice, st)) != hipSuccess) break;
+    if ((e = hipMemcpyAsync(dC, C, vb, hipMemcpyHostToDevice, st)) != hipSuccess) break;
+    rc = qap_witness_dev(dA, dB, dC, m, omega, g, dH, dW, wsb, st);
+    if (rc) break;
+    if ((e = hipMemcpyAsync(H, dH, hb, hipMemcpyDeviceToHost, st)) != hipSuccess) break;
+    e = hipStreamSynchronize(st);
+  } while (0);
+  hipFree(d);
+  hipStreamDestroy(st);
+  if (rc) return rc;
+  if (e != hipSuccess) return fail(OZK_E_NO_DEVICE, "HIP failure in qap_witness_host: %s", hipGetErrorString(e));
+  return OZK_OK;
 }
 
 int ozk_fft_host(const uint8_t* in, int32_t n, const uint8_t* omega, int32_t task_id, uint8_t* out) {

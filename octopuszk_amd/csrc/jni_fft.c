@@ -46,3 +46,47 @@ JNIEXPORT jbyteArray JNICALL Java_algebra_fft_FFTAuxiliary_serialRadix2FFTNative
   free(out);
   return result;
 }
+
+/* OPTIONAL native (no counterpart in the reference): the whole witness map on the GPU. */
+static int ozk_small_le(JNIEnv* env, jbyteArray arr, uint8_t out[32], const char* name) {
+  memset(out, 0, 32);
+  if (!arr) { ozk_throw(env, "null byte[] argument"); return 0; }
+  const jsize len = (*env)->GetArrayLength(env, arr);
+  if (len > 32) {
+    char buf[96];
+    snprintf(buf, sizeof(buf), "%s longer than 32 bytes", name);
+    ozk_throw(env, buf);
+    return 0;
+  }
+  (*env)->GetByteArrayRegion(env, arr, 0, len, (jbyte*)out);
+  return 1;
+}
+
+JNIEXPORT jbyteArray JNICALL Java_algebra_fft_FFTAuxiliary_qapWitnessNativeHelper(
+    JNIEnv* env, jclass cls, jbyteArray a, jbyteArray b, jbyteArray c, jint m, jbyteArray omega, jbyteArray g,
+    jint taskID) {
+  (void)cls;
+  if (m < 2 || (m & (m - 1))) return ozk_throw(env, "QAP domain size must be a power of two >= 2");
+  uint8_t om[32], gg[32];
+  if (!ozk_small_le(env, omega, om, "omega") || !ozk_small_le(env, g, gg, "g")) return NULL;
+  const long long need = 32LL * m;
+  jbyte* pa = ozk_borrow(env, a, need, "A");
+  jbyte* pb = pa ? ozk_borrow(env, b, need, "B") : NULL;
+  jbyte* pc = pb ? ozk_borrow(env, c, need, "C") : NULL;
+  jbyteArray result = NULL;
+  if (pc) {
+    uint8_t* out = (uint8_t*)malloc((size_t)(need + 32));
+    if (!out) ozk_throw(env, "out of host memory");
+    else {
+      const int rc = ozk_qap_witness_host((const uint8_t*)pa, (const uint8_t*)pb, (const uint8_t*)pc, m, om, gg,
+                                          taskID, out);
+      if (rc) ozk_throw_last(env, "qapWitnessNativeHelper", rc);
+      else result = ozk_result(env, out, need + 32);
+      free(out);
+    }
+  }
+  if (pc) ozk_release(env, c, pc);
+  if (pb) ozk_release(env, b, pb);
+  if (pa) ozk_release(env, a, pa);
+  return result;
+}

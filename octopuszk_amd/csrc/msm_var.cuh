@@ -684,15 +684,12 @@ struct RunAcc<CV, false> {
 };
 
 template <class CV, bool FIRST>
-__global__ void __launch_bounds__(256)
-k_segreduce(const u32* __restrict__ bid_in, const u32* __restrict__ idx_in,
-            const u32* __restrict__ pts_in,  // FIRST: affine bases; else Jacobian slots
-            const u32* __restrict__ d_count, int n_in_static, int L,
-            u32* __restrict__ buckets, u32* __restrict__ bid_out, u32* __restrict__ pts_out,
-            int n_lanes) {
+__device__ __forceinline__ void
+segreduce_lane(const int t, const u32* __restrict__ bid_in, const u32* __restrict__ idx_in,
+               const u32* __restrict__ pts_in,  // FIRST: affine bases; else Jacobian slots
+               const u32* __restrict__ d_count, int n_in_static, int L,
+               u32* __restrict__ buckets, u32* __restrict__ bid_out, u32* __restrict__ pts_out) {
   using IO = CurveIO<CV>;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n_lanes) return;
   // levels >= 2: d_count is the number of partial slots still alive after the run merge;
   // 0 means every bucket is already complete and the level has nothing to do
   if (!FIRST && *d_count == 0) return;
@@ -758,6 +755,38 @@ k_segreduce(const u32* __restrict__ bid_in, const u32* __restrict__ idx_in,
   }
   bid_out[2 * (size_t)t] = head_bid;
   bid_out[2 * (size_t)t + 1] = tail_bid;
+}
+
+template <class CV, bool FIRST>
+__global__ void __launch_bounds__(256)
+k_segreduce(const u32* __restrict__ bid_in, const u32* __restrict__ idx_in, const u32* __restrict__ pts_in,
+            const u32* __restrict__ d_count, int n_in_static, int L,
+            u32* __restrict__ buckets, u32* __restrict__ bid_out, u32* __restrict__ pts_out,
+            int n_lanes) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_lanes) return;
+  segreduce_lane<CV, FIRST>(t, bid_in, idx_in, pts_in, d_count, n_in_static, L, buckets, bid_out, pts_out);
+}
+
+// The last generic levels (a few hundred lanes and fewer) in ONE single-block launch instead of one
+// 6-us launch per level: level after level with a block barrier in between, ping-ponging between the
+// two slot arrays, until one lane has seen everything.  Ends with the result in the buckets.
+template <class CV>
+__global__ void __launch_bounds__(256)
+k_segreduce_small(const u32* __restrict__ d_count, int n_in, int L, u32* __restrict__ buckets,
+                  u32* __restrict__ bid_a, u32* __restrict__ pts_a, u32* __restrict__ bid_b, u32* __restrict__ pts_b) {
+  if (*d_count == 0) return;
+  u32 *bi = bid_a, *pi = pts_a, *bo = bid_b, *po = pts_b;
+  while (true) {
+    const int lanes = (n_in + L - 1) / L;
+    for (int t = threadIdx.x; t < lanes; t += blockDim.x)
+      segreduce_lane<CV, false>(t, bi, nullptr, pi, d_count, n_in, L, buckets, bo, po);
+    if (lanes == 1) break;
+    __syncthreads();  // (also orders the global writes of this level before the next level's reads)
+    n_in = 2 * lanes;
+    u32* tb = bi; bi = bo; bo = tb;
+    u32* tp = pi; pi = po; po = tp;
+  }
 }
 
 // Run merge between level 1 and the generic levels.  After level 1 a bucket cut by lane

@@ -292,8 +292,14 @@ static int var_msm_accum(int n, void* sorted, size_t sorted_bytes, void* accum_w
   // (they return at once when nothing survived)
   int cur = 0;
   bool first_generic = true;
+  const int small_lanes = env_int("OZK_MSM_SMALL_LEVEL_LANES", 1024);
   while (true) {
     lanes = (n_in + p.LK - 1) / p.LK;
+    if (!first_generic && (int)lanes <= small_lanes) {  // the remaining levels in one single-block launch
+      hipLaunchKernelGGL((k_segreduce_small<CT>), dim3(1), dim3(TB), 0, st, L.total + 1, (int)n_in, p.LK, L.buckets,
+                         L.slot_bid[cur], L.slot_pts[cur], L.slot_bid[cur ^ 1], L.slot_pts[cur ^ 1]);
+      break;
+    }
     hipLaunchKernelGGL((k_segreduce<CT, false>), dim3((unsigned)((lanes + TB - 1) / TB)), dim3(TB), 0, st,
                        first_generic ? L.slot_bid2 : L.slot_bid[cur], (const u32*)nullptr, L.slot_pts[cur],
                        L.total + 1, (int)n_in, p.LK, L.buckets, L.slot_bid[cur ^ 1], L.slot_pts[cur ^ 1], (int)lanes);

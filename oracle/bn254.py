@@ -477,6 +477,37 @@ def radix2_coset_inverse_fft(a: List[int], g: int, p: int = R) -> None:
     multiply_by_coset(a, pow(g, -1, p), p)
 
 
+def compute_z(t: int, domain_size: int, p: int = R) -> int:
+    """SerialFFT.java:143-145: the vanishing polynomial of S at t."""
+    return (pow(t, domain_size, p) - 1) % p
+
+
+def divide_by_z_on_coset(a: List[int], coset: int, p: int = R) -> None:
+    """SerialFFT.java:158-163."""
+    zinv = pow(compute_z(coset, len(a), p), -1, p)
+    for i in range(len(a)):
+        a[i] = (a[i] * zinv) % p
+
+
+def qap_witness_coefficients_h(a_eval: Sequence[int], b_eval: Sequence[int], c_eval: Sequence[int],
+                               g: int = FR_MULT_GEN, p: int = R) -> List[int]:
+    """R1CStoQAP.R1CStoQAPWitness from the evaluations on (R1CStoQAP.java:163-230): returns
+    coefficientsH, domainSize + 1 entries."""
+    A, B, C = list(a_eval), list(b_eval), list(c_eval)
+    radix2_inverse_fft(A, p)        # :166-167
+    radix2_inverse_fft(B, p)
+    radix2_coset_fft(A, g, p)       # :173-174
+    radix2_coset_fft(B, g, p)
+    H = [(x * y) % p for x, y in zip(A, B)]   # :180-183
+    radix2_inverse_fft(C, p)        # :201
+    radix2_coset_fft(C, g, p)       # :207
+    H = [(h - c) % p for h, c in zip(H, C)]   # :213-216
+    divide_by_z_on_coset(H, g, p)   # :224
+    radix2_coset_inverse_fft(H, g, p)  # :229
+    H.append(0)                     # :230
+    return H
+
+
 def naive_dft(a: Sequence[int], omega: int, p: int = R) -> List[int]:
     """Polynomial evaluation at omega^i — what SerialFFTTest.java:168-190
     compares the FFT with."""

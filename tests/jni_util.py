@@ -95,3 +95,13 @@ def fft(elements, omega, task=0):
                     omega, ctypes.c_long(len(omega)), task, out, ctypes.c_long(max(n, 1) * 64), err,
                     ctypes.byref(refs))
     return _finish(rc, out, err), refs.value
+
+
+def qap_witness(a, b, c, m, omega, g, task=0):
+    mk = mock()
+    cap = 32 * (m + 1)
+    out, err = ctypes.create_string_buffer(cap), ctypes.create_string_buffer(1024)
+    mk.mock_qap_witness.restype = ctypes.c_long
+    rc = mk.mock_qap_witness(SHIM_FFT.encode(), a, b, c, ctypes.c_long(len(a)), m, omega, ctypes.c_long(len(omega)),
+                             g, ctypes.c_long(len(g)), task, out, ctypes.c_long(cap), err)
+    return _finish(rc, out, err)

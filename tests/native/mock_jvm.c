@@ -199,3 +199,15 @@ long mock_fft(const char* lib, const unsigned char* data, const long* offs, cons
   free(l.items); fr(om);
   return rc;
 }
+
+typedef jbyteArray (*fn_qap)(JNIEnv*, jclass, jbyteArray, jbyteArray, jbyteArray, jint, jbyteArray, jbyteArray, jint);
+long mock_qap_witness(const char* lib, const void* a, const void* b, const void* c, long vl, int m, const void* omega,
+                      long ol, const void* g, long gl, int task, unsigned char* out, long cap, char* err) {
+  fn_qap f = (fn_qap)sym(lib, "Java_algebra_fft_FFTAuxiliary_qapWitnessNativeHelper", err);
+  if (!f) return -9;
+  JNIEnv* e = env();
+  MArray *ma = mk(a, vl), *mb = mk(b, vl), *mc = mk(c, vl), *mo = mk(omega, ol), *mg = mk(g, gl);
+  long rc = finish(f(e, NULL, ma, mb, mc, m, mo, mg, task), out, cap, err);
+  fr(ma); fr(mb); fr(mc); fr(mo); fr(mg);
+  return rc;
+}

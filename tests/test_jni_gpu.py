@@ -60,3 +60,20 @@ def test_jni_fft_list_walk():
     o.serial_radix2_fft(b, w)
     assert got == b"".join(int(x).to_bytes(64, "little") for x in b)
     assert refs == n                         # every element's local reference was deleted
+
+
+def test_jni_optional_qap_witness_native():
+    # not a native of the reference: the optional binding of INTEGRATION.md §5
+    rng = random.Random(45)
+    m = 128
+    a = [rng.randrange(o.R) for _ in range(m)]
+    b = [rng.randrange(o.R) for _ in range(m)]
+    c = [x * y % o.R for x, y in zip(a, b)]
+    enc = lambda v: b"".join(o.to_le32(x) for x in v)
+    got = ju.qap_witness(enc(a), enc(b), enc(c), m, o.to_fft_bytes(o.fr_root_of_unity(m)), o.to_fft_bytes(o.FR_MULT_GEN))
+    want = o.qap_witness_coefficients_h(a, b, c)
+    assert got == enc(want)
+    with pytest.raises(ju.JavaException):
+        ju.qap_witness(enc(a)[:-32], enc(b), enc(c), m, o.to_le32(o.fr_root_of_unity(m)), o.to_le32(5))
+    with pytest.raises(ju.JavaException):
+        ju.qap_witness(enc(a), enc(b), enc(c), 96, o.to_le32(1), o.to_le32(5))

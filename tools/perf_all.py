@@ -121,6 +121,20 @@ def main():
         out0 = int.from_bytes(bytes(d_out[:64].cpu().numpy()), "little")
         s = sum(int.from_bytes(r.tobytes(), "little") for r in a) % o.R
         print("FFT Fr     n=2^%-2d      %8.3f ms  %8.1f Melem/s  %6.1f GB/s (64 B/elem)  ok=%s" % (logn, ms, n / ms / 1e3, n * 64 / ms / 1e6, out0 == s), flush=True)
+    # ---- QAP witness map (7 transforms + pointwise stages), device-resident
+    for logm in (16, 21):
+        m = 1 << logm
+        ev = [torch.from_numpy(scalars(m, 40 + k).reshape(-1)).cuda() for k in range(3)]
+        d_h = torch.empty((m + 1) * 32, dtype=torch.uint8, device="cuda")
+        wsb = int(L.ozk_qap_witness_workspace_bytes(m))
+        wsf = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+        om = ctypes.create_string_buffer(o.to_le32(o.fr_root_of_unity(m)), 32)
+        gg = ctypes.create_string_buffer(o.to_le32(o.FR_MULT_GEN), 32)
+        fn = lambda: ozk.check(L.ozk_qap_witness_dev(ptr(ev[0]), ptr(ev[1]), ptr(ev[2]), m, ctypes.cast(om, ctypes.c_void_p),
+                                                     ctypes.cast(gg, ctypes.c_void_p), ptr(d_h), ptr(wsf), wsb, st))
+        ms = timeit(fn, 10)
+        # 3 x 32 B in + 32 B out per domain point
+        print("QAP witness m=2^%-2d     %8.3f ms  %8.1f Mpoint/s  %6.1f GB/s (128 B/point)" % (logm, ms, m / ms / 1e3, m * 128 / ms / 1e6), flush=True)
 
 
 if __name__ == "__main__":
