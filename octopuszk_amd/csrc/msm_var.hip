@@ -34,9 +34,24 @@ static MsmPlan make_plan(int n) {
   p.n_in = n;
   p.glv = env_int("OZK_MSM_GLV", 1) != 0 && n <= GLV_MAX_N;
   p.n = p.glv ? 2 * n : n;
-  int c = ilog2((uint32_t)p.n) - 4;
-  if (c < 4) c = 4;
-  if (c > 16) c = 16;
+  // Window size by cost model: bucket additions (points x windows) plus ~3.4 addition-equivalents
+  // per bucket for the window sums (two Jacobian additions of 16-18 multiplications against 10 for a
+  // mixed XYZZ addition).  A window count that leaves the top window nearly empty (c = 15 over 128
+  // bits: 9 windows, the ninth 7 bits wide) also piles thousands of entries into a few buckets and
+  // wakes the generic reduction levels — measured on G2 at 2^18: 8.1 ms with c = 15, the model's
+  // c = 16 avoids it.
+  const int sd_ok = p.glv && env_int("OZK_MSM_SIGNED", 1) != 0;
+  const int bits = p.glv ? 128 : 256;
+  int c = 4;
+  double best = 1e300;
+  for (int k = 4; k <= 16; k++) {
+    const double W = (double)((bits + k - 1) / k);
+    const double cost = (double)p.n * W + 3.4 * W * (double)(1u << (k - sd_ok));
+    if (cost < best) {
+      best = cost;
+      c = k;
+    }
+  }
   c = env_int("OZK_MSM_C", c);
   if (c < 1) c = 1;
   if (c > 16) c = 16;
