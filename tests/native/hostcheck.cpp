@@ -17,6 +17,8 @@ static void fe_binop(int op, const u32* a, const u32* b, u32* out) {
     case 2: from_mont(add(x, y), wo); break;
     case 3: from_mont(sub(x, y), wo); break;
     case 4: from_mont(inv(x), wo); break;
+    case 9: from_mont(inv_fermat(x), wo); break;
+    case 10: { auto big = sub(dbl(dbl(dbl(x))), y); from_mont(inv(big), wo); break; }  // non-canonical, bound > 128
     case 5: from_mont(neg(x), wo); break;
     case 6: from_mont(dbl(dbl(dbl(x))), wo); break;
     case 7: { auto t = sub(sub(sub(x, y), y), y); from_mont(reduce_to<32>(t), wo); break; }

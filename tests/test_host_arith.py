@@ -59,7 +59,22 @@ def test_field_ops(hc, field, p):
         assert fe_op(hc, field, 8, a) == a
     for a in vals[:40]:
         want = pow(a, -1, p) if a % p else 0
-        assert fe_op(hc, field, 4, a) == want
+        assert fe_op(hc, field, 9, a) == want      # Fermat
+
+
+@pytest.mark.parametrize("field,p", [("fq", o.Q), ("fr", o.R)])
+def test_safegcd_inversion(hc, field, p):
+    # the divstep inversion against modular exponentiation, edge values, zero, non-canonical input
+    rng = random.Random(8)
+    vals = EDGE(p) + [p, p + 1, (1 << 256) - 1, (1 << 30) - 1, 1 << 30, (1 << 30) + 1, 1 << 60, (1 << 255) + 7]
+    vals += [rng.randrange(p) for _ in range(2000)] + [rng.randrange(1 << b) for b in range(1, 255, 2)]
+    for a in vals:
+        want = pow(a % p, -1, p) if a % p else 0
+        assert fe_op(hc, field, 4, a) == want, hex(a)
+    for a in vals[:60]:
+        b = vals[(7 * a + 3) % len(vals)] if False else vals[(vals.index(a) * 7 + 3) % len(vals)]
+        big = (8 * a - b) % p
+        assert fe_op(hc, field, 10, a, b) == (pow(big, -1, p) if big else 0)
 
 
 def test_noncanonical_input_reduced(hc):
