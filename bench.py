@@ -49,6 +49,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--logn", type=int, default=LOGN)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prepared", action="store_true",
+                    help="bases prepared once outside the timed region (ozk_var_msm_prepare_dev): NOT the "
+                         "BASELINE.json workload, whose every MSM starts from the JNI wire bytes")
     ap.add_argument("--in-flight", type=int, default=2,
                     help="MSMs in flight: the latency-bound tail of step k runs on a side stream while the "
                          "head of step k+1 runs (1 = strictly serial steps)")
@@ -79,6 +82,7 @@ def main():
     sc_host = rand_scalars(n, 1 + rank)
     scalars = torch.from_numpy(sc_host).cuda()
     pipe = dev.VarMsmPipeline(n, 1, depth=max(1, args.in_flight))
+    msm_bases = pipe.prepare(bases) if args.prepared else bases
     wb, wn = ctypes.c_int32(), ctypes.c_int32()
     ozk.check(L.ozk_var_msm_plan(n, ctypes.byref(wb), ctypes.byref(wn)))
     glv = int(L.ozk_var_msm_glv(n))
@@ -105,7 +109,7 @@ def main():
         """k complete MSMs; step i's tail overlaps step i+1's head (args.in_flight > 1)."""
         res, prev = None, None
         for _ in range(k):
-            t = pipe.submit(bases, scalars)
+            t = pipe.submit(msm_bases, scalars, prepared=args.prepared)
             if pipe.depth == 1:
                 res = finish(t)
                 continue
@@ -135,7 +139,7 @@ def main():
     for _ in range(5):
         torch.cuda.synchronize()
         l0 = time.perf_counter()
-        finish(pipe.submit(bases, scalars))
+        finish(pipe.submit(msm_bases, scalars, prepared=args.prepared))
         torch.cuda.synchronize()
         lat.append(time.perf_counter() - l0)
     single_ms = sorted(lat)[len(lat) // 2] * 1e3
@@ -192,6 +196,7 @@ def main():
                 "config": {"workload": "VariableBaseMSM BN254 G1 2^%d random scalars/bases per GPU, bit-exact vs "
                                        "the serial CPU path (BASELINE.json configs[1])" % args.logn,
                            "n_per_gpu": n, "window_bits": wb.value, "windows": wn.value, "glv": bool(glv),
+                           "prepared_bases": bool(args.prepared),
                            "msms_in_flight": max(1, args.in_flight), "single_msm_latency_ms": round(single_ms, 3),
                            "parallelism": "index-range shard x%d, RCCL all-gather of 192-B partials + HIP point sum" % world},
                 "roofline": roofline, "cpu_baseline": cpu}

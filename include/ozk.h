@@ -74,6 +74,26 @@ int ozk_var_msm_dev(const void* d_bases, const void* d_scalars, int32_t n, int32
  * normalisation; a few lanes busy for ~2 ms) and reads nothing but `d_tail`.  Running the tail
  * on a second stream lets the next MSM's head (which may reuse the same workspace) overlap
  * it.  ozk_var_msm_dev == head + tail on one stream. */
+/* ---- prepared bases (no counterpart in the reference, which re-marshals and
+ * re-uploads the proving key for every MSM, VariableBaseMSM.java:224-227).  The bases are converted once
+ * to the affine Montgomery records the accumulation kernel gathers (with the GLV plan: both halves,
+ * 2n x 64 | 128 B) and stay in HBM; an MSM over them skips the conversion and the 96 | 192 B per base of
+ * host-to-device traffic.  Results are byte-identical to ozk_var_msm_host on the same inputs.
+ *   host form : handle = create(bases) ; msm(handle, scalars) any number of times ; destroy(handle).
+ *               A handle serialises its MSMs (internal mutex); use one handle per concurrent caller.
+ *   device form: ozk_var_msm_prepare_dev once, then ozk_var_msm_prepared_dev / _head_prepared_dev. */
+int ozk_bases_create_host(const uint8_t* bases, int32_t n, int32_t type, int32_t task_id, void** handle);
+int ozk_var_msm_bases_host(void* handle, const uint8_t* scalars, int32_t n, uint8_t* out);
+int ozk_bases_destroy(void* handle);
+size_t ozk_var_msm_prepared_bytes(int32_t n, int32_t type);
+int ozk_var_msm_prepare_dev(const void* d_bases, int32_t n, int32_t type, void* d_prepared, size_t prepared_size,
+                            void* stream);
+int ozk_var_msm_prepared_dev(const void* d_prepared, const void* d_scalars, int32_t n, int32_t type, void* d_out,
+                             void* d_workspace, size_t workspace_bytes, void* stream);
+int ozk_var_msm_head_prepared_dev(const void* d_prepared, const void* d_scalars, int32_t n, int32_t type,
+                                  void* d_workspace, size_t workspace_bytes, void* d_tail, size_t tail_bytes,
+                                  void* stream, void* previous_levels_done);
+
 /* Ordering hint for several MSMs in flight on two streams.  The bucket accumulation of MSM k+1 fills
  * every SIMD's register file; if it is dispatched before the single-wave Horner kernel of MSM k is
  * resident, that kernel waits for a free slot (+0.7 ms) and then starves the accumulation blocks next

@@ -65,6 +65,24 @@ OZK_HD bool digit_decode(u32 code, int sd, u32& b, u32& neg) {
   }
   return code != 0;
 }
+// Signed recoding of one half scalar |k| < 2^126.97 (glv.cuh) whose sign `neg` is folded into every
+// digit: sum_w sign_w (b_w + 1) 2^(c w) = (neg ? -|k| : |k|).  Carry-propagated; the top digit stays
+// below 2^(c-1), so no carry leaves the top window.  The u16 code has room for 2^16 - 1 non-zero
+// values, one short of +-[1, 2^15] at c = 16: digits of a positive half scalar are recoded to
+// (-2^15, 2^15], those of a negative one to [-2^15, 2^15), so that after the fold -2^15 never occurs.
+template <class Emit>
+OZK_HD void signed_digit_codes(const u32 (&e)[8], int c, int W, bool neg, Emit emit) {
+  const u32 half = 1u << (c - 1);
+  const u32 thr = (c == 16 && neg) ? half - 1u : half;
+  u32 cy = 0;
+  for (int w = 0; w < W; w++) {
+    const u32 d = scalar_digit(e, w, c) + cy;
+    cy = d > thr;
+    const u32 m = cy ? (1u << c) - d : d;
+    emit(w, (uint16_t)(m ? (((m - 1u) << 1) | (cy ^ (u32)neg)) + 1u : 0u));
+  }
+}
+
 // Packed coarse word: index << 8 | lo8, lo8 = low bucket bits (8 unsigned / 7 signed) | neg << 7 (signed).
 // In the sorted index array the sign travels in bit 31.
 constexpr u32 SIDX_NEG = 0x80000000u;
@@ -83,11 +101,13 @@ OZK_HD Fe<FqParams, 16> glv_beta() {
   else return fe_const<FqParams, 16>(GlvConsts::BETA_G1);
 }
 
-// With GLV (neg != nullptr; k_digits has run): record i = (x, +-y), record n + i = (beta x, +-y), the
-// signs being those of the two half scalars, so that nothing downstream knows about signs.
+// With GLV: record i = (x, y), record n + i = (beta x, y).  Signed-digit plans fold the signs of the
+// two half scalars into the digit signs (k_digits_glv), so the records depend on the bases alone —
+// which is what makes them reusable across MSMs (ozk_var_msm_prepare_dev).  Unsigned GLV plans
+// (neg_flags != nullptr; k_digits_glv has run) write (x, +-y), (beta x, +-y) instead.
 template <class CV>
 __global__ void __launch_bounds__(256) k_convert_bases(const u32* __restrict__ wire,
-                                                       u32* __restrict__ aff, int n,
+                                                       u32* __restrict__ aff, int n, int glv,
                                                        const uint8_t* __restrict__ neg_flags) {
   using IO = CurveIO<CV>;
   using EA = typename CV::EA;
@@ -118,16 +138,18 @@ __global__ void __launch_bounds__(256) k_convert_bases(const u32* __restrict__ w
   // canonical (< p) so that equal points have equal records
   q.x = EA(canonical(q.x));
   q.y = EA(canonical(q.y));
-  if (neg_flags == nullptr) {
+  if (!glv) {
     IO::store_aff(q, o);
     return;
   }
   Aff<EA> q2;
   q2.x = EA(canonical(scale(q.x, glv_beta<CV>())));
   q2.y = q.y;
-  const EA ny = EA(canonical(neg(q.y)));   // infinity marker (0, 0) stays (0, 0)
-  if (neg_flags[i]) q.y = ny;
-  if (neg_flags[n + i]) q2.y = ny;
+  if (neg_flags != nullptr) {
+    const EA ny = EA(canonical(neg(q.y)));   // infinity marker (0, 0) stays (0, 0)
+    if (neg_flags[i]) q.y = ny;
+    if (neg_flags[n + i]) q2.y = ny;
+  }
   IO::store_aff(q, o);
   IO::store_aff(q2, aff + (size_t)(n + i) * IO::AFF_WORDS);
 }
@@ -147,7 +169,8 @@ __global__ void __launch_bounds__(256) k_digits(const u32* __restrict__ scalars,
 }
 
 // GLV form: scalar i (reduced mod r) -> |k1|, |k2| < 2^127 (glv.cuh); virtual scalar i = |k1| and
-// n + i = |k2| of a 2n-point MSM with W = ceil(128 / c) windows; the signs go to neg_flags for
+// n + i = |k2| of a 2n-point MSM with W = ceil(128 / c) windows.  Signed-digit plans XOR the sign of
+// the half scalar into every digit's sign; unsigned plans leave the signs in neg_flags for
 // k_convert_bases.
 __global__ void __launch_bounds__(256) k_digits_glv(const u32* __restrict__ scalars, int n, int c, int W, int sd,
                                                     uint16_t* __restrict__ digits, uint8_t* __restrict__ neg_flags) {
@@ -165,17 +188,9 @@ __global__ void __launch_bounds__(256) k_digits_glv(const u32* __restrict__ scal
   u32 e2[8] = {k2[0], k2[1], k2[2], k2[3], 0, 0, 0, 0};
   const size_t ne = 2 * (size_t)n;
   if (sd) {
-    // carry-propagated signed digits; |k| < 2^127 (glv.cuh) keeps the top digit within (-2^(c-1), 2^(c-1)]
-    const u32 half = 1u << (c - 1);
-    u32 cy1 = 0, cy2 = 0;
-    for (int w = 0; w < W; w++) {
-      u32 d1 = scalar_digit(e1, w, c) + cy1, d2 = scalar_digit(e2, w, c) + cy2;
-      cy1 = d1 > half;
-      cy2 = d2 > half;
-      const u32 m1 = cy1 ? (1u << c) - d1 : d1, m2 = cy2 ? (1u << c) - d2 : d2;
-      digits[(size_t)w * ne + i] = (uint16_t)(m1 ? (((m1 - 1u) << 1) | cy1) + 1u : 0u);
-      digits[(size_t)w * ne + n + i] = (uint16_t)(m2 ? (((m2 - 1u) << 1) | cy2) + 1u : 0u);
-    }
+    signed_digit_codes(e1, c, W, n1, [&](int w, uint16_t code) { digits[(size_t)w * ne + i] = code; });
+    signed_digit_codes(e2, c, W, n2, [&](int w, uint16_t code) { digits[(size_t)w * ne + n + i] = code; });
+    return;
   } else {
     for (int w = 0; w < W; w++) {
       digits[(size_t)w * ne + i] = (uint16_t)scalar_digit(e1, w, c);

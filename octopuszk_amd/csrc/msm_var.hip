@@ -1,6 +1,7 @@
 // Variable-base MSM: host driver + C ABI (include/ozk.h).
 // Replaces pippengerMSMG1 / pippengerMSMG2 (algebra_msm_VariableBaseMSM.cu:1246-1604) and
 // the two JNI natives of algebra.msm.VariableBaseMSM (.cu:1614-1788).
+#include <pthread.h>
 #include <stdlib.h>
 
 #include <vector>
@@ -101,7 +102,8 @@ struct RegionBytes {
   size_t sorted, sort_ws, accum_ws;
 };
 template <class CV>
-static MsmLayout make_layout3(const MsmPlan& p, void* sorted, void* sort_ws, void* accum_ws, RegionBytes* rb) {
+static MsmLayout make_layout3(const MsmPlan& p, void* sorted, void* sort_ws, void* accum_ws, RegionBytes* rb,
+                              const void* prepared = nullptr) {
   using IO = CurveIO<CV>;
   MsmLayout L;
   L.cap = (size_t)p.n * p.W;
@@ -113,6 +115,7 @@ static MsmLayout make_layout3(const MsmPlan& p, void* sorted, void* sort_ws, voi
   L.nC1 = (size_t)p.W * L.NH * L.nblk;
   Bump a(sorted, ~(size_t)0);
   L.aff = a.take<u32>((size_t)p.n * IO::AFF_WORDS);
+  if (prepared) L.aff = (u32*)prepared;  // affine records kept across MSMs (ozk_var_msm_prepare_dev)
   L.hist = a.take<u32>(L.NB);
   L.total = a.take<u32>(4);
   L.sidx = a.take<u32>(L.cap);
@@ -219,10 +222,12 @@ static void launch_wsum0(const MsmPlan& p, const MsmLayout& L, hipStream_t st, i
 // leaves the "sorted set".
 template <class CV>
 static int var_msm_sort(const void* d_bases, const void* d_scalars, int n, void* sorted, size_t sorted_bytes,
-                        void* sort_ws, size_t sort_ws_bytes, hipStream_t st, hipEvent_t order_ev = nullptr) {
+                        void* sort_ws, size_t sort_ws_bytes, hipStream_t st, hipEvent_t order_ev = nullptr,
+                        const void* prepared = nullptr) {
   const MsmPlan p = make_plan(n);
+  if (prepared && p.glv && !p.sd) return fail(OZK_E_INVALID, "prepared bases need the signed-digit plan");
   RegionBytes rb;
-  const MsmLayout L = make_layout3<CV>(p, sorted, sort_ws, nullptr, &rb);
+  const MsmLayout L = make_layout3<CV>(p, sorted, sort_ws, nullptr, &rb, prepared);
   if (rb.sorted > sorted_bytes || rb.sort_ws > sort_ws_bytes)
     return fail(OZK_E_INVALID, "sort buffers too small: need %zu + %zu bytes, got %zu + %zu", rb.sorted, rb.sort_ws,
                 sorted_bytes, sort_ws_bytes);
@@ -235,11 +240,13 @@ static int var_msm_sort(const void* d_bases, const void* d_scalars, int n, void*
   if (p.glv) {
     hipLaunchKernelGGL(k_digits_glv, dim3((n_in + TB - 1) / TB), dim3(TB), 0, st, scalars, n_in, p.c, p.W, p.sd,
                        L.digits, L.neg_flags);
-    hipLaunchKernelGGL((k_convert_bases<CV>), dim3((n_in + TB - 1) / TB), dim3(TB), 0, st, bases, L.aff, n_in,
-                       (const uint8_t*)L.neg_flags);
+    if (!prepared)
+      hipLaunchKernelGGL((k_convert_bases<CV>), dim3((n_in + TB - 1) / TB), dim3(TB), 0, st, bases, L.aff, n_in, 1,
+                         p.sd ? (const uint8_t*)nullptr : (const uint8_t*)L.neg_flags);
   } else {
-    hipLaunchKernelGGL((k_convert_bases<CV>), dim3((n_in + TB - 1) / TB), dim3(TB), 0, st, bases, L.aff, n_in,
-                       (const uint8_t*)nullptr);
+    if (!prepared)
+      hipLaunchKernelGGL((k_convert_bases<CV>), dim3((n_in + TB - 1) / TB), dim3(TB), 0, st, bases, L.aff, n_in, 0,
+                         (const uint8_t*)nullptr);
     hipLaunchKernelGGL(k_digits, dim3((n_in + TB - 1) / TB), dim3(TB), 0, st, scalars, n_in, p.c, p.W, L.digits);
   }
   // two-level counting sort by (window, digit): per-block LDS counts of the hi part, one global
@@ -280,11 +287,11 @@ static int var_msm_sort(const void* d_bases, const void* d_scalars, int n, void*
 // Vector-ALU-bound.  Reads the sorted set, leaves W * 2^c / S window-sum elements in the tail buffers.
 template <class CV>
 static int var_msm_accum(int n, void* sorted, size_t sorted_bytes, void* accum_ws, size_t accum_ws_bytes, void* tail,
-                         size_t tail_bytes, hipStream_t st) {
+                         size_t tail_bytes, hipStream_t st, const void* prepared = nullptr) {
   using CT = CV;  // (an out-of-line-multiplication variant for the tails measured 40 % slower)
   const MsmPlan p = make_plan(n);
   RegionBytes rb;
-  MsmLayout L = make_layout3<CV>(p, sorted, nullptr, accum_ws, &rb);
+  MsmLayout L = make_layout3<CV>(p, sorted, nullptr, accum_ws, &rb, prepared);
   if (rb.sorted > sorted_bytes || rb.accum_ws > accum_ws_bytes)
     return fail(OZK_E_INVALID, "accumulate buffers too small: need %zu + %zu bytes, got %zu + %zu", rb.sorted,
                 rb.accum_ws, sorted_bytes, accum_ws_bytes);
@@ -333,15 +340,16 @@ static int var_msm_accum(int n, void* sorted, size_t sorted_bytes, void* accum_w
 // Head = SORT + ACCUMULATE on one stream, the three regions carved from one workspace.
 template <class CV>
 static int var_msm_head(const void* d_bases, const void* d_scalars, int n, void* ws, size_t ws_bytes, void* tail,
-                        size_t tail_bytes, hipStream_t st, hipEvent_t order_ev = nullptr) {
+                        size_t tail_bytes, hipStream_t st, hipEvent_t order_ev = nullptr,
+                        const void* prepared = nullptr) {
   const RegionBytes rb = region_bytes<CV>(n);
   if (rb.sorted + rb.sort_ws + rb.accum_ws > ws_bytes)
     return fail(OZK_E_INVALID, "workspace too small: need %zu bytes, got %zu", rb.sorted + rb.sort_ws + rb.accum_ws,
                 ws_bytes);
   uint8_t* w = (uint8_t*)ws;
-  int rc = var_msm_sort<CV>(d_bases, d_scalars, n, w, rb.sorted, w + rb.sorted, rb.sort_ws, st, order_ev);
+  int rc = var_msm_sort<CV>(d_bases, d_scalars, n, w, rb.sorted, w + rb.sorted, rb.sort_ws, st, order_ev, prepared);
   if (rc) return rc;
-  return var_msm_accum<CV>(n, w, rb.sorted, w + rb.sorted + rb.sort_ws, rb.accum_ws, tail, tail_bytes, st);
+  return var_msm_accum<CV>(n, w, rb.sorted, w + rb.sorted + rb.sort_ws, rb.accum_ws, tail, tail_bytes, st, prepared);
 }
 
 // Tail phase: the latency-bound remainder (wave-cooperative window-sum levels, Horner over the
@@ -414,14 +422,14 @@ static size_t var_msm_tail_bytes(int n) {
 // head + tail on one stream, the tail buffers carved from the end of the workspace
 template <class CV>
 static int var_msm_dev(const void* d_bases, const void* d_scalars, int n, void* d_out, void* ws,
-                       size_t ws_bytes, hipStream_t st) {
+                       size_t ws_bytes, hipStream_t st, const void* prepared = nullptr) {
   const RegionBytes rb0 = region_bytes<CV>(n);
   const size_t main_bytes = rb0.sorted + rb0.sort_ws + rb0.accum_ws;
   const size_t tb = var_msm_tail_bytes<CV>(n);
   if (main_bytes + tb > ws_bytes)
     return fail(OZK_E_INVALID, "workspace too small: need %zu bytes, got %zu", main_bytes + tb, ws_bytes);
   uint8_t* tail = (uint8_t*)ws + main_bytes;
-  int rc = var_msm_head<CV>(d_bases, d_scalars, n, ws, main_bytes, tail, tb, st);
+  int rc = var_msm_head<CV>(d_bases, d_scalars, n, ws, main_bytes, tail, tb, st, nullptr, prepared);
   if (rc) return rc;
   return var_msm_tail<CV>(n, tail, tb, d_out, st);
 }
@@ -474,6 +482,93 @@ static int var_msm_host(const uint8_t* bases, const uint8_t* scalars, int n, int
   return OZK_OK;
 }
 
+// ---- prepared bases: the affine Montgomery records (GLV: both halves) of a base
+// array, kept in HBM across MSMs.  A Groth16 proving key is fixed; the reference re-marshals and
+// re-uploads it for every proof (VariableBaseMSM.java:224-227).
+template <class CV>
+static size_t prepared_bytes(int n) {
+  const MsmPlan p = make_plan(n);
+  return (((size_t)p.n * CurveIO<CV>::AFF_WORDS * sizeof(u32)) + 255) & ~(size_t)255;
+}
+template <class CV>
+static int var_msm_prepare(const void* d_bases, int n, void* d_prepared, size_t bytes, hipStream_t st) {
+  const MsmPlan p = make_plan(n);
+  if (p.glv && !p.sd) return fail(OZK_E_INVALID, "prepared bases need the signed-digit plan");
+  if (bytes < prepared_bytes<CV>(n)) return fail(OZK_E_INVALID, "prepared buffer too small");
+  hipLaunchKernelGGL((k_convert_bases<CV>), dim3((n + 255) / 256), dim3(256), 0, st, (const u32*)d_bases,
+                     (u32*)d_prepared, n, p.glv, (const uint8_t*)nullptr);
+  OZK_HIP(hipGetLastError());
+  return OZK_OK;
+}
+
+// Host-side handle: prepared bases + everything an MSM over them needs, allocated once.
+struct BasesHandle {
+  int device, n, type;
+  hipStream_t st;
+  uint8_t *d_prepared, *d_scalars, *d_out, *d_ws;
+  size_t ws_bytes;
+  pthread_mutex_t mu;
+};
+
+template <class CV>
+static int bases_create(const uint8_t* bases, int n, int type, int task_id, BasesHandle** out) {
+  using IO = CurveIO<CV>;
+  int rc = select_device(task_id);
+  if (rc) return rc;
+  BasesHandle* h = (BasesHandle*)calloc(1, sizeof(BasesHandle));
+  if (!h) return fail(OZK_E_NOMEM, "out of host memory");
+  hipGetDevice(&h->device);
+  h->n = n;
+  h->type = type;
+  pthread_mutex_init(&h->mu, nullptr);
+  const size_t wire = (size_t)n * IO::WIRE_JAC_WORDS * 4, pb = prepared_bytes<CV>(n);
+  h->ws_bytes = var_msm_ws_bytes<CV>(n);
+  hipError_t e = hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking);
+  uint8_t* d_wire = nullptr;
+  if (e == hipSuccess) e = hipMalloc((void**)&h->d_prepared, pb);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->d_scalars, (size_t)n * 32 + 256);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->d_out, 1024);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->d_ws, h->ws_bytes);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_wire, wire);
+  rc = OZK_OK;
+  if (e == hipSuccess) e = hipMemcpyAsync(d_wire, bases, wire, hipMemcpyHostToDevice, h->st);
+  if (e == hipSuccess) rc = var_msm_prepare<CV>(d_wire, n, h->d_prepared, pb, h->st);
+  if (e == hipSuccess && !rc) e = hipStreamSynchronize(h->st);
+  if (d_wire) hipFree(d_wire);
+  if (e != hipSuccess || rc) {
+    if (h->d_prepared) hipFree(h->d_prepared);
+    if (h->d_scalars) hipFree(h->d_scalars);
+    if (h->d_out) hipFree(h->d_out);
+    if (h->d_ws) hipFree(h->d_ws);
+    if (h->st) hipStreamDestroy(h->st);
+    free(h);
+    if (rc) return rc;
+    return fail(OZK_E_NOMEM, "HIP failure while preparing bases: %s", hipGetErrorString(e));
+  }
+  *out = h;
+  return OZK_OK;
+}
+
+template <class CV>
+static int bases_msm(BasesHandle* h, const uint8_t* scalars, uint8_t* out) {
+  const size_t out_bytes = (size_t)CurveIO<CV>::WIRE_JAC_WORDS * 8;
+  pthread_mutex_lock(&h->mu);
+  int rc = OZK_OK;
+  hipError_t e = hipSetDevice(h->device);
+  do {
+    if (e != hipSuccess) break;
+    if ((e = hipMemcpyAsync(h->d_scalars, scalars, (size_t)h->n * 32, hipMemcpyHostToDevice, h->st)) != hipSuccess) break;
+    rc = var_msm_dev<CV>(nullptr, h->d_scalars, h->n, h->d_out, h->d_ws, h->ws_bytes, h->st, h->d_prepared);
+    if (rc) break;
+    if ((e = hipMemcpyAsync(out, h->d_out, out_bytes, hipMemcpyDeviceToHost, h->st)) != hipSuccess) break;
+    e = hipStreamSynchronize(h->st);
+  } while (0);
+  pthread_mutex_unlock(&h->mu);
+  if (rc) return rc;
+  if (e != hipSuccess) return fail(OZK_E_NO_DEVICE, "HIP failure in MSM over prepared bases: %s", hipGetErrorString(e));
+  return OZK_OK;
+}
+
 }  // namespace ozk
 
 using namespace ozk;
@@ -521,6 +616,68 @@ int ozk_var_msm_head_dev(const void* d_bases, const void* d_scalars, int32_t n, 
   return var_msm_head<G2Cfg>(d_bases, d_scalars, n, d_workspace, workspace_bytes, d_tail, tail_bytes,
                              (hipStream_t)stream);
 }
+size_t ozk_var_msm_prepared_bytes(int32_t n, int32_t type) {
+  if (n <= 0 || n > (1 << 24)) return 0;
+  return type == OZK_G1 ? prepared_bytes<G1Cfg>(n) : prepared_bytes<G2Cfg>(n);
+}
+int ozk_var_msm_prepare_dev(const void* d_bases, int32_t n, int32_t type, void* d_prepared, size_t prepared_size,
+                            void* stream) {
+  if (!d_bases || !d_prepared) return fail(OZK_E_INVALID, "null pointer argument");
+  if (n <= 0 || n > (1 << 24)) return fail(OZK_E_INVALID, "batch_size %d out of range [1, 2^24]", n);
+  if (type == OZK_G1) return var_msm_prepare<G1Cfg>(d_bases, n, d_prepared, prepared_size, (hipStream_t)stream);
+  return var_msm_prepare<G2Cfg>(d_bases, n, d_prepared, prepared_size, (hipStream_t)stream);
+}
+int ozk_var_msm_head_prepared_dev(const void* d_prepared, const void* d_scalars, int32_t n, int32_t type,
+                                  void* d_workspace, size_t workspace_bytes, void* d_tail, size_t tail_bytes,
+                                  void* stream, void* previous_levels_done) {
+  if (!d_prepared || !d_scalars || !d_workspace || !d_tail) return fail(OZK_E_INVALID, "null pointer argument");
+  if (n <= 0 || n > (1 << 24)) return fail(OZK_E_INVALID, "batch_size %d out of range [1, 2^24]", n);
+  if (type == OZK_G1)
+    return var_msm_head<G1Cfg>(nullptr, d_scalars, n, d_workspace, workspace_bytes, d_tail, tail_bytes,
+                               (hipStream_t)stream, (hipEvent_t)previous_levels_done, d_prepared);
+  return var_msm_head<G2Cfg>(nullptr, d_scalars, n, d_workspace, workspace_bytes, d_tail, tail_bytes,
+                             (hipStream_t)stream, (hipEvent_t)previous_levels_done, d_prepared);
+}
+int ozk_var_msm_prepared_dev(const void* d_prepared, const void* d_scalars, int32_t n, int32_t type, void* d_out,
+                             void* d_workspace, size_t workspace_bytes, void* stream) {
+  if (!d_prepared || !d_scalars || !d_out || !d_workspace) return fail(OZK_E_INVALID, "null pointer argument");
+  if (n <= 0 || n > (1 << 24)) return fail(OZK_E_INVALID, "batch_size %d out of range [1, 2^24]", n);
+  if (type == OZK_G1)
+    return var_msm_dev<G1Cfg>(nullptr, d_scalars, n, d_out, d_workspace, workspace_bytes, (hipStream_t)stream,
+                              d_prepared);
+  return var_msm_dev<G2Cfg>(nullptr, d_scalars, n, d_out, d_workspace, workspace_bytes, (hipStream_t)stream,
+                            d_prepared);
+}
+int ozk_bases_create_host(const uint8_t* bases, int32_t n, int32_t type, int32_t task_id, void** handle) {
+  if (!bases || !handle) return fail(OZK_E_INVALID, "null pointer argument");
+  if (n <= 0 || n > (1 << 24)) return fail(OZK_E_INVALID, "batch_size %d out of range [1, 2^24]", n);
+  BasesHandle* h = nullptr;
+  const int rc = type == OZK_G1 ? bases_create<G1Cfg>(bases, n, type, task_id, &h)
+                                : bases_create<G2Cfg>(bases, n, type, task_id, &h);
+  if (!rc) *handle = h;
+  return rc;
+}
+int ozk_var_msm_bases_host(void* handle, const uint8_t* scalars, int32_t n, uint8_t* out) {
+  if (!handle || !scalars || !out) return fail(OZK_E_INVALID, "null pointer argument");
+  BasesHandle* h = (BasesHandle*)handle;
+  if (n != h->n) return fail(OZK_E_INVALID, "batch_size %d does not match the prepared bases (%d)", n, h->n);
+  return h->type == OZK_G1 ? bases_msm<G1Cfg>(h, scalars, out) : bases_msm<G2Cfg>(h, scalars, out);
+}
+int ozk_bases_destroy(void* handle) {
+  if (!handle) return OZK_OK;
+  BasesHandle* h = (BasesHandle*)handle;
+  hipSetDevice(h->device);
+  hipStreamSynchronize(h->st);
+  hipFree(h->d_prepared);
+  hipFree(h->d_scalars);
+  hipFree(h->d_out);
+  hipFree(h->d_ws);
+  hipStreamDestroy(h->st);
+  pthread_mutex_destroy(&h->mu);
+  free(h);
+  return OZK_OK;
+}
+
 int ozk_order_event_create(void** ev) {
   if (!ev) return fail(OZK_E_INVALID, "null pointer argument");
   hipEvent_t e = nullptr;

@@ -81,16 +81,25 @@ class VarMsmPipeline:
         except Exception:
             pass
 
-    def submit(self, d_bases, d_scalars):
+    def prepare(self, d_bases):
+        """Affine Montgomery records of `d_bases` (wire format) for submit(..., prepared=True): done once
+        per proving key, skips the conversion kernel in every MSM."""
+        L = _lib.load()
+        nbytes = int(L.ozk_var_msm_prepared_bytes(self.n, self.type))
+        out = torch.empty(nbytes, dtype=torch.uint8, device=d_bases.device)
+        _lib.check(L.ozk_var_msm_prepare_dev(_ptr(d_bases), self.n, self.type, _ptr(out), nbytes, _stream()))
+        return out
+
+    def submit(self, d_bases, d_scalars, prepared=False):
         L = _lib.load()
         slot = self.count % self.depth
         main = torch.cuda.current_stream()
         if self.count >= self.depth:
             main.wait_event(self.tail_done[slot])      # the tail that last used this slot's buffers
         prev = self.levels_done[(self.count - 1) % self.depth] if (self.count and self.depth > 1) else None
-        _lib.check(L.ozk_var_msm_head_ordered_dev(_ptr(d_bases), _ptr(d_scalars), self.n, self.type, _ptr(self.ws),
-                                                  self.ws_bytes, _ptr(self.tails[slot]), self.tail_bytes,
-                                                  int(main.cuda_stream), prev))
+        head = L.ozk_var_msm_head_prepared_dev if prepared else L.ozk_var_msm_head_ordered_dev
+        _lib.check(head(_ptr(d_bases), _ptr(d_scalars), self.n, self.type, _ptr(self.ws), self.ws_bytes,
+                        _ptr(self.tails[slot]), self.tail_bytes, int(main.cuda_stream), prev))
         self.head_done[slot].record(main)
         self.side.wait_event(self.head_done[slot])
         _lib.check(L.ozk_var_msm_tail_ordered_dev(self.n, self.type, _ptr(self.tails[slot]), self.tail_bytes,

@@ -33,6 +33,13 @@ _SIGS = {
     "ozk_var_msm_tail_bytes": (sz, [i32, i32]),
     "ozk_var_msm_head_dev": (ctypes.c_int, [vp, vp, i32, i32, vp, sz, vp, sz, vp]),
     "ozk_var_msm_tail_dev": (ctypes.c_int, [i32, i32, vp, sz, vp, vp]),
+    "ozk_bases_create_host": (ctypes.c_int, [vp, i32, i32, i32, ctypes.POINTER(vp)]),
+    "ozk_var_msm_bases_host": (ctypes.c_int, [vp, vp, i32, vp]),
+    "ozk_bases_destroy": (ctypes.c_int, [vp]),
+    "ozk_var_msm_prepared_bytes": (sz, [i32, i32]),
+    "ozk_var_msm_prepare_dev": (ctypes.c_int, [vp, i32, i32, vp, sz, vp]),
+    "ozk_var_msm_prepared_dev": (ctypes.c_int, [vp, vp, i32, i32, vp, vp, sz, vp]),
+    "ozk_var_msm_head_prepared_dev": (ctypes.c_int, [vp, vp, i32, i32, vp, sz, vp, sz, vp, vp]),
     "ozk_order_event_create": (ctypes.c_int, [ctypes.POINTER(vp)]),
     "ozk_order_event_destroy": (ctypes.c_int, [vp]),
     "ozk_var_msm_head_ordered_dev": (ctypes.c_int, [vp, vp, i32, i32, vp, sz, vp, sz, vp, vp]),

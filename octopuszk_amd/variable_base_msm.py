@@ -88,3 +88,34 @@ def serial_msm(scalars, bases, group_add, group_zero, is_g1=True, task_id=0):
     for g in results:
         final = group_add(final, g)
     return final
+
+
+class PreparedBases:
+    """Bases kept on the GPU across MSMs (include/ozk.h "prepared bases").  The
+    reference marshals and uploads the proving-key slice for every call (VariableBaseMSM.java:224-227);
+    with a handle only the scalars travel.  Same bytes out as variable_base_serial_msm_native_helper."""
+
+    def __init__(self, bases_xyz: bytes, batch_size: int, type_: int, task_id: int = 0):
+        L = _lib.load()
+        self._h = ctypes.c_void_p()
+        self.n, self.type = batch_size, type_
+        _lib.check(L.ozk_bases_create_host(ctypes.cast(ctypes.c_char_p(bases_xyz), ctypes.c_void_p), batch_size, type_,
+                                           task_id, ctypes.byref(self._h)))
+
+    def msm(self, scalars: bytes) -> bytes:
+        L = _lib.load()
+        out = ctypes.create_string_buffer(192 if self.type == 1 else 384)
+        _lib.check(L.ozk_var_msm_bases_host(self._h, ctypes.cast(ctypes.c_char_p(scalars), ctypes.c_void_p),
+                                            len(scalars) // 32, ctypes.cast(out, ctypes.c_void_p)))
+        return out.raw
+
+    def close(self):
+        if self._h:
+            _lib.load().ozk_bases_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -164,3 +164,10 @@ extern "C" void hc_glv_beta(u32* out) {
   from_mont(fe_const<FqParams, 16>(GlvConsts::BETA_G2), w);
   memcpy(out + 8, w, 32);
 }
+
+// ---- signed digit recoding (msm_var.cuh): codes of one 128-bit half scalar
+#include "../../octopuszk_amd/csrc/msm_var.cuh"
+extern "C" void hc_signed_digits(const u32* k4, int c, int W, int neg, uint16_t* codes) {
+  u32 e[8] = {k4[0], k4[1], k4[2], k4[3], 0, 0, 0, 0};
+  signed_digit_codes(e, c, W, neg != 0, [&](int w, uint16_t code) { codes[w] = code; });
+}

@@ -60,3 +60,32 @@ def test_endomorphism_identity(hc):
     Q2 = o.G2.to_affine(o.G2.mul(o.G2.one, 0xfeedbeef6789))
     phi = ((b2 * Q2[0][0] % o.Q, b2 * Q2[0][1] % o.Q), Q2[1], (1, 0))
     assert o.G2.equals(phi, o.G2.mul(Q2, LAM))
+
+
+def test_signed_digit_recoding(hc):
+    """sum_w sign_w (b_w + 1) 2^(c w) == +-|k| for every window size, with the half scalar's sign
+    folded in; at c = 16 the code must never need magnitude 2^15 with a minus sign (u16 overflow)."""
+    rng = random.Random(9)
+    bound = 1 << 127
+    for c in (2, 4, 5, 8, 13, 15, 16):
+        W = (128 + c - 1) // c
+        ks = [0, 1, (1 << 126) + 12345, int(2 ** 126.96), 0x8000, 0x8000 << 16, 0x7fff8000, 0x80008000,
+              (0x8000 << 96) | (0x8000 << 32) | 0x8000, (1 << 112) * 32000 + 0xffff, sum(0x8000 << (16 * j) for j in range(7))]
+        ks += [rng.randrange(bound // 2) for _ in range(300)]
+        for k in ks:
+            if c == 4 and k >> 124 >= 7:
+                continue   # (the proven bound 2^126.97 leaves the top nibble < 8)
+            for neg in (0, 1):
+                codes = (ctypes.c_uint16 * W)()
+                words = (ctypes.c_uint32 * 4)(*[(k >> (32 * i)) & 0xffffffff for i in range(4)])
+                hc.hc_signed_digits(words, c, W, neg, codes)
+                total = 0
+                for w in range(W):
+                    code = codes[w]
+                    if code == 0:
+                        continue
+                    t = code - 1
+                    b, s = t >> 1, t & 1
+                    assert b < (1 << (c - 1))
+                    total += (-(b + 1) if s else (b + 1)) << (c * w)
+                assert total == (-k if neg else k), (c, hex(k), neg)

@@ -18,7 +18,7 @@ LIB = os.path.join(HERE, "native", "_hostcheck.so")
 @pytest.fixture(scope="module")
 def hc():
     deps = [SRC] + [os.path.join(HERE, "..", "octopuszk_amd", "csrc", f)
-                    for f in ("fp29.cuh", "ec.cuh", "fq2.cuh", "glv.cuh", "consts_gen.h")]
+                    for f in ("fp29.cuh", "ec.cuh", "fq2.cuh", "glv.cuh", "msm_var.cuh", "curve.cuh", "consts_gen.h")]
     deps = [d for d in deps if os.path.exists(d)]
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-shared", "-fPIC", "-o", LIB, SRC])

@@ -299,3 +299,49 @@ def test_glv_off_equals_glv_on(type_, monkeypatch):
     monkeypatch.setenv("OZK_MSM_GLV", "0")
     off = run(scalars, bases)
     assert on == off
+
+
+# ---- prepared bases (include/ozk.h): same bytes as the per-call path ----
+@pytest.mark.parametrize("type_", [1, 2])
+def test_prepared_bases_equal_per_call_path(type_):
+    from octopuszk_amd import variable_base_msm as vb, lib
+    G = o.G1 if type_ == 1 else o.G2
+    rng = random.Random(70 + type_)
+    n = 500 if type_ == 1 else 120
+    bases = _rand_points(G, n // 2, rng) + _rand_points(G, n - n // 2, rng, affine=False)   # Z = 1 and Z != 1
+    bases[3] = G.zero
+    wire = vb.marshal_g1(bases) if type_ == 1 else vb.marshal_g2(bases)
+    pb = vb.PreparedBases(wire, n, type_, 0)
+    for k in range(3):   # one handle, several MSMs
+        scalars = [rng.randrange(o.R) for _ in range(n)]
+        scalars[0], scalars[1] = 0, o.R - 1
+        sw = vb.marshal_scalars(scalars)
+        got = pb.msm(sw)
+        assert got == vb.variable_base_serial_msm_native_helper(wire, sw, n, type_, 0)
+        if k == 0:
+            want = G.to_affine(o.naive_msm(G, scalars, bases))
+            assert got == (o.g1_out_le(want) if type_ == 1 else o.g2_out_le(want))
+    with pytest.raises(lib.OzkError):
+        pb.msm(vb.marshal_scalars([1] * (n - 1)))
+    pb.close()
+
+
+def test_prepared_pipeline_full_size():
+    import torch
+    from octopuszk_amd import device as dev
+    n = 1 << 20
+    bases = dev.gen_g1_bases(n, seed=77)
+    rng = random.Random(78)
+    import numpy as np
+    sc = np.random.default_rng(79).integers(0, 256, size=(3, n, 32), dtype=np.uint8)
+    sc[:, :, 31] &= 0x1F
+    pipe = dev.VarMsmPipeline(n, 1, depth=2)
+    prep = pipe.prepare(bases)
+    outs = []
+    for k in range(3):
+        d_sc = torch.from_numpy(sc[k].reshape(-1)).cuda()
+        a = bytes(pipe.result(pipe.submit(bases, d_sc)).cpu().numpy())
+        b = bytes(pipe.result(pipe.submit(prep, d_sc, prepared=True)).cpu().numpy())
+        assert a == b
+        outs.append(a)
+    assert len(set(outs)) == 3
