@@ -355,6 +355,16 @@ JNIEXPORT jbyteArray JNICALL Java_algebra_fft_FFTAuxiliary_serialRadix2FFTNative
 JNIEXPORT jbyteArray JNICALL Java_algebra_fft_FFTAuxiliary_qapWitnessNativeHelper(
     JNIEnv* env, jclass cls, jbyteArray a, jbyteArray b, jbyteArray c, jint m, jbyteArray omega, jbyteArray g,
     jint taskID);
+/* ([BIII)J / (J[BII)[B / (J)V — prepared bases: upload and convert a base array
+ * once, run any number of MSMs over it (only the scalars travel), release it.  ozk_bases_create_host,
+ * ozk_var_msm_bases_host, ozk_bases_destroy.  The bytes returned equal those of
+ * variableBaseSerialMSMNativeHelper on the same inputs. */
+JNIEXPORT jlong JNICALL Java_algebra_msm_VariableBaseMSM_prepareBasesNativeHelper(
+    JNIEnv* env, jclass cls, jbyteArray bases, jint batch_size, jint type, jint taskID);
+JNIEXPORT jbyteArray JNICALL Java_algebra_msm_VariableBaseMSM_variableBaseSerialMSMPreparedNativeHelper(
+    JNIEnv* env, jclass cls, jlong handle, jbyteArray scalars, jint batch_size, jint type);
+JNIEXPORT void JNICALL Java_algebra_msm_VariableBaseMSM_releaseBasesNativeHelper(JNIEnv* env, jclass cls,
+                                                                                 jlong handle);
 
 #ifdef __cplusplus
 }

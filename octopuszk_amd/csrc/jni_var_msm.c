@@ -39,3 +39,40 @@ JNIEXPORT jbyteArray JNICALL Java_algebra_msm_VariableBaseMSM_variableBaseDouble
   if (rc) return ozk_throw_last(env, "variableBaseDoubleMSMNativeHelper", rc);
   return ozk_result(env, out, 576);
 }
+
+/* ---- OPTIONAL natives (not declared by the reference's Java): bases kept on the GPU
+ * across MSMs.  The handle travels through Java as a long. */
+JNIEXPORT jlong JNICALL Java_algebra_msm_VariableBaseMSM_prepareBasesNativeHelper(
+    JNIEnv* env, jclass cls, jbyteArray bases, jint batch_size, jint type, jint taskID) {
+  (void)cls;
+  if (batch_size <= 0) { ozk_throw(env, "batch_size must be positive"); return 0; }
+  const long long pt = type == OZK_G1 ? 96 : 192;
+  jbyte* b = ozk_borrow(env, bases, pt * batch_size, "bases");
+  if (!b) return 0;
+  void* h = NULL;
+  const int rc = ozk_bases_create_host((const uint8_t*)b, batch_size, type, taskID, &h);
+  ozk_release(env, bases, b);
+  if (rc) { ozk_throw_last(env, "prepareBasesNativeHelper", rc); return 0; }
+  return (jlong)(intptr_t)h;
+}
+
+JNIEXPORT jbyteArray JNICALL Java_algebra_msm_VariableBaseMSM_variableBaseSerialMSMPreparedNativeHelper(
+    JNIEnv* env, jclass cls, jlong handle, jbyteArray scalars, jint batch_size, jint type) {
+  (void)cls;
+  if (!handle) return ozk_throw(env, "null bases handle");
+  if (batch_size <= 0) return ozk_throw(env, "batch_size must be positive");
+  jbyte* s = ozk_borrow(env, scalars, 32LL * batch_size, "scalars");
+  if (!s) return NULL;
+  uint8_t out[384];
+  const int rc = ozk_var_msm_bases_host((void*)(intptr_t)handle, (const uint8_t*)s, batch_size, out);
+  ozk_release(env, scalars, s);
+  if (rc) return ozk_throw_last(env, "variableBaseSerialMSMPreparedNativeHelper", rc);
+  return ozk_result(env, out, type == OZK_G1 ? 192 : 384);
+}
+
+JNIEXPORT void JNICALL Java_algebra_msm_VariableBaseMSM_releaseBasesNativeHelper(JNIEnv* env, jclass cls,
+                                                                                 jlong handle) {
+  (void)env;
+  (void)cls;
+  ozk_bases_destroy((void*)(intptr_t)handle);
+}

@@ -105,3 +105,12 @@ def qap_witness(a, b, c, m, omega, g, task=0):
     rc = mk.mock_qap_witness(SHIM_FFT.encode(), a, b, c, ctypes.c_long(len(a)), m, omega, ctypes.c_long(len(omega)),
                              g, ctypes.c_long(len(g)), task, out, ctypes.c_long(cap), err)
     return _finish(rc, out, err)
+
+
+def prepared_msm(bases, scalars, n, type_, task=0, reps=2):
+    m = mock()
+    out, err = ctypes.create_string_buffer(384), ctypes.create_string_buffer(1024)
+    m.mock_prepared_msm.restype = ctypes.c_long
+    rc = m.mock_prepared_msm(SHIM_VAR.encode(), bases, ctypes.c_long(len(bases)), scalars, ctypes.c_long(len(scalars)),
+                             n, type_, task, reps, out, ctypes.c_long(384), err)
+    return _finish(rc, out, err)

@@ -211,3 +211,33 @@ long mock_qap_witness(const char* lib, const void* a, const void* b, const void*
   fr(ma); fr(mb); fr(mc); fr(mo); fr(mg);
   return rc;
 }
+
+typedef jlong (*fn_prep)(JNIEnv*, jclass, jbyteArray, jint, jint, jint);
+typedef jbyteArray (*fn_prep_msm)(JNIEnv*, jclass, jlong, jbyteArray, jint, jint);
+typedef void (*fn_rel)(JNIEnv*, jclass, jlong);
+/* prepare once, run `reps` MSMs with the same scalars (outputs must agree), release */
+long mock_prepared_msm(const char* lib, const void* bases, long bl, const void* sc, long sl, int n, int type, int task,
+                       int reps, unsigned char* out, long cap, char* err) {
+  fn_prep fp = (fn_prep)sym(lib, "Java_algebra_msm_VariableBaseMSM_prepareBasesNativeHelper", err);
+  fn_prep_msm fm = (fn_prep_msm)sym(lib, "Java_algebra_msm_VariableBaseMSM_variableBaseSerialMSMPreparedNativeHelper", err);
+  fn_rel fr_ = (fn_rel)sym(lib, "Java_algebra_msm_VariableBaseMSM_releaseBasesNativeHelper", err);
+  if (!fp || !fm || !fr_) return -9;
+  JNIEnv* e = env();
+  MArray *a = mk(bases, bl), *b = mk(sc, sl);
+  jlong h = fp(e, NULL, a, n, type, task);
+  long rc = -1;
+  if (g_exc_pending || !h) {
+    snprintf(err, 512, "%s", g_exc_pending ? g_exc : "null handle without exception");
+  } else if (g_live_pins != 0) {
+    snprintf(err, 512, "shim leaked %d pinned arrays", g_live_pins);
+    rc = -2;
+  } else {
+    for (int k = 0; k < reps; k++) {
+      rc = finish(fm(e, NULL, h, b, n, type), out, cap, err);
+      if (rc < 0) break;
+    }
+    fr_(e, NULL, h);
+  }
+  fr(a); fr(b);
+  return rc;
+}

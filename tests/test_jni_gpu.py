@@ -77,3 +77,19 @@ def test_jni_optional_qap_witness_native():
         ju.qap_witness(enc(a)[:-32], enc(b), enc(c), m, o.to_le32(o.fr_root_of_unity(m)), o.to_le32(5))
     with pytest.raises(ju.JavaException):
         ju.qap_witness(enc(a), enc(b), enc(c), 96, o.to_le32(1), o.to_le32(5))
+
+
+def test_jni_optional_prepared_bases_natives():
+    # prepareBases / ...PreparedNativeHelper / releaseBases: same bytes as the plain native
+    rng = random.Random(46)
+    n = 200
+    for type_, C, wire in ((1, o.G1, o.g1_to_wire), (2, o.G2, o.g2_to_wire)):
+        pts = _pts(C, n if type_ == 1 else 60, rng)
+        k = len(pts)
+        bw = b"".join(wire(P) for P in pts)
+        sw = b"".join(o.to_le32(rng.randrange(o.R)) for _ in range(k))
+        assert ju.prepared_msm(bw, sw, k, type_) == ju.var_msm(bw, sw, k, type_)
+    with pytest.raises(ju.JavaException):
+        ju.prepared_msm(bw[:-8], sw, k, 2)          # short bases array -> exception from prepare
+    with pytest.raises(ju.JavaException):
+        ju.prepared_msm(bw, sw[:-32], k, 2)         # short scalars -> exception from the MSM call
