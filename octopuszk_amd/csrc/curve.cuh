@@ -164,6 +164,18 @@ struct CurveIO {
 };
 
 #if defined(__HIPCC__)
+// Workgroup barrier with an EXPLICIT wait for this wave's outstanding LDS and global operations.
+// __syncthreads() is supposed to imply it, but hipcc (ROCm 7.2, gfx950) leaves the s_waitcnt out when
+// the pending operation is a non-returning LDS atomic issued in a loop whose back edge jumps over the
+// barrier block: k_sortbig_count read its counters before the last ds_add_u32 of another wave had
+// landed and lost exactly one wave-instruction's worth of counts (64, or all 24 of a short last chunk)
+// — found with tools/diag_sortbig.py, visible in the ISA as `ds_add_u32 ... s_branch ... s_barrier`
+// with no s_waitcnt in between.  Every barrier in this library goes through here.
+__device__ __forceinline__ void block_sync() {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
 // hipcc scalarises a provably wave-uniform computation onto the SALU, where the 64-bit
 // MAD chains run ~4x slower (measured: 11.6 us per doubling); an opaque zero in a VGPR
 // keeps serial single-lane tails on the vector ALU.

@@ -111,7 +111,7 @@ __device__ __forceinline__ void fft_stages(u32* lds, const PassArgs& a, int T, i
     lds_store(lds, e0, Fe<FrP, BIN + 32>(add(x, t)));
     lds_store(lds, e1, Fe<FrP, BIN + 32>(sub(x, t)));
   }
-  __syncthreads();
+  block_sync();
   if constexpr (Q < FFT_MAXK) fft_stages<Q + 1, BIN + 32>(lds, a, T, logT, u0);
 }
 
@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(FFT_THREADS) k_fft_pass(PassArgs a, int last) 
     // FIRST: arbitrary 256-bit wire value (bound 85); later passes: stored < 4p
     lds_store(lds, mid * T + ul, unpack<FrP, 85>(w));
   }
-  __syncthreads();
+  block_sync();
   constexpr int B0 = 96;  // >= 85 (any 256-bit input) and >= 64 (inter-pass storage)
   fft_stages<1, B0>(lds, a, T, logT, u0);
   // after K stages the bound is B0 + 32*K <= B0 + 32*FFT_MAXK
@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(FFT_THREADS) k_fft_small(const u32* __restrict
 #pragma unroll
     for (int k = 0; k < 8; k++) scratch[(size_t)i * 8 + k] = o[k];
   }
-  __syncthreads();
+  block_sync();
   for (int s = 1; s <= logn; s++) {
     const int m = 1 << (s - 1);
     for (int b = threadIdx.x; b < n / 2; b += FFT_THREADS) {
@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(FFT_THREADS) k_fft_small(const u32* __restrict
 #pragma unroll
       for (int k = 0; k < 8; k++) scratch[(size_t)(k0 + m) * 8 + k] = o[k];
     }
-    __syncthreads();
+    block_sync();
   }
   for (int i = threadIdx.x; i < n; i += FFT_THREADS) {
     u32 o[8];

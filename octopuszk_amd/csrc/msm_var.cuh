@@ -216,7 +216,9 @@ constexpr int SORT_CHUNK = 4096;
 constexpr int SORT_BLOCK = 256;
 
 // LDS atomic add of 1 with wave aggregation when every live lane has the same key
+template <bool AGGREGATE = true>
 __device__ __forceinline__ u32 lds_rank(u32* cnt, u32 key, bool live) {
+  if constexpr (!AGGREGATE) return live ? atomicAdd(&cnt[key], 1u) : 0u;
   const unsigned long long m = __ballot(live);
   u32 r = 0;
   if (m != 0ull) {
@@ -241,7 +243,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sort1_count(const uint16_t* __re
   extern __shared__ u32 cnt[];
   const int w = blockIdx.y, blk = blockIdx.x;
   for (int h = threadIdx.x; h < NH; h += SORT_BLOCK) cnt[h] = 0;
-  __syncthreads();
+  block_sync();
   const int i0 = blk * SORT_CHUNK;
   constexpr int PER = SORT_CHUNK / SORT_BLOCK;
   u32 dreg[PER];  // all loads first (independent, pipelined), then the LDS atomics
@@ -256,7 +258,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sort1_count(const uint16_t* __re
     const bool live = digit_decode(dreg[k], sd, b, neg);
     lds_rank(cnt, b >> lo_bits, live);
   }
-  __syncthreads();
+  block_sync();
   for (int h = threadIdx.x; h < NH; h += SORT_BLOCK) C1[((size_t)w * NH + h) * nblk + blk] = cnt[h];
 }
 
@@ -292,7 +294,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sort1_scatter(const uint16_t* __
     if (lane >= o) incl += x;
   }
   if (lane == 63) wsum[t >> 6] = incl;
-  __syncthreads();
+  block_sync();
   u32 woff = 0;
   for (int k = 0; k < (t >> 6); k++) woff += wsum[k];
   const u32 excl = woff + incl - ct;
@@ -301,7 +303,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sort1_scatter(const uint16_t* __
     gdelta[t] = g0 - excl;
   }
   if (t == SORT_BLOCK - 1) n_local = woff + incl;
-  __syncthreads();
+  block_sync();
   const int i0 = blk * SORT_CHUNK;
   const u32 lo_mask = (1u << lo_bits) - 1u;
   constexpr int PER = SORT_CHUNK / SORT_BLOCK;
@@ -323,7 +325,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sort1_scatter(const uint16_t* __
       dest[r] = r + gdelta[hi];
     }
   }
-  __syncthreads();
+  block_sync();
   const u32 m = n_local;
   for (u32 j = t; j < m; j += SORT_BLOCK) coarse[dest[j]] = stage[j];
 }
@@ -333,6 +335,9 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sort1_scatter(const uint16_t* __
 // them into SORTBIG_CHUNK-entry work items, k_sortbig_count / _scan / _scatter run the same
 // count - scan - ranked-scatter scheme over those items with a fixed grid.  With no big bin the
 // three kernels return at once.
+#ifndef OZK_SORTBIG_AGG
+#define OZK_SORTBIG_AGG true
+#endif
 constexpr u32 SORT_BIG = 1u << 16;
 constexpr u32 SORTBIG_CHUNK = 1u << 13;
 constexpr int SORTBIG_MAXBINS = 1024;   // >= number of bins that can exceed SORT_BIG: cap / SORT_BIG
@@ -346,7 +351,7 @@ __global__ void __launch_bounds__(256) k_sortbig_list(const u32* __restrict__ P1
                                                       BigBins* __restrict__ bb) {
   __shared__ u32 n_big, n_items;
   if (threadIdx.x == 0) n_big = n_items = 0;
-  __syncthreads();
+  block_sync();
   for (int bin = threadIdx.x; bin < nbins; bin += blockDim.x) {
     const u32 b0 = P1[(size_t)bin * nblk];
     const u32 b1 = (bin + 1 < nbins) ? P1[(size_t)(bin + 1) * nblk] : *total;
@@ -362,7 +367,7 @@ __global__ void __launch_bounds__(256) k_sortbig_list(const u32* __restrict__ P1
       }
     }
   }
-  __syncthreads();
+  block_sync();
   if (threadIdx.x == 0) {
     // big_thresh >= n/64 bounds the number of big bins by 64 * W <= SORTBIG_MAXBINS
     bb->n_big = n_big < (u32)SORTBIG_MAXBINS ? n_big : (u32)SORTBIG_MAXBINS;
@@ -395,18 +400,18 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sortbig_count(const u32* __restr
     u32 r, k;
     if (!sortbig_item(bb, item, r, k)) continue;
     cnt[threadIdx.x] = 0;
-    __syncthreads();
+    block_sync();
     const u32 lo0 = bb->b0[r] + k * SORTBIG_CHUNK;
     const u32 end = bb->b0[r] + bb->size[r];
     const u32 hi0 = (lo0 + SORTBIG_CHUNK < end) ? lo0 + SORTBIG_CHUNK : end;
     for (u32 e = lo0 + threadIdx.x; e - threadIdx.x < hi0; e += SORT_BLOCK) {
       const bool live = e < hi0;
       const u32 v = live ? coarse[e] : 0u;
-      lds_rank(cnt, v & lo_mask, live);
+      lds_rank<OZK_SORTBIG_AGG>(cnt, v & lo_mask, live);
     }
-    __syncthreads();
+    block_sync();
     T[(size_t)item * 256 + threadIdx.x] = cnt[threadIdx.x];
-    __syncthreads();
+    block_sync();
   }
 }
 
@@ -430,7 +435,7 @@ __global__ void __launch_bounds__(256) k_sortbig_scan(const BigBins* __restrict_
     if (lane >= o) incl += x;
   }
   if (lane == 63) wsum[t >> 6] = incl;
-  __syncthreads();
+  block_sync();
   u32 woff = 0;
   for (int q = 0; q < (t >> 6); q++) woff += wsum[q];
   u32 run = bb->b0[r] + woff + incl - tot;
@@ -456,7 +461,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sortbig_scatter(const u32* __res
     u32 r, k;
     if (!sortbig_item(bb, item, r, k)) continue;
     cur[threadIdx.x] = T[(size_t)item * 256 + threadIdx.x];
-    __syncthreads();
+    block_sync();
     const int bin = (int)bb->bin[r];
     const int w = bin / NH, h = bin - w * NH;
     const u32 bucket0 = ((u32)w << c) | ((u32)h << lo_bits);
@@ -467,13 +472,13 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sortbig_scatter(const u32* __res
       const bool live = e < hi0;
       const u32 v = live ? coarse[e] : 0u;
       const u32 lo = v & lo_mask;
-      const u32 pos = lds_rank(cur, lo, live);
+      const u32 pos = lds_rank<OZK_SORTBIG_AGG>(cur, lo, live);
       if (live) {
         sidx[pos] = (v >> 8) | ((v & sign_bit) << 24);
         sbid[pos] = bucket0 + lo;
       }
     }
-    __syncthreads();
+    block_sync();
   }
 }
 
@@ -495,7 +500,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sort2(const u32* __restrict__ co
   const u32 bucket0 = ((u32)w << c) | ((u32)h << lo_bits);
   if (b1 - b0 > big_thresh) return;  // split over many blocks by the k_sortbig_* kernels
   if (threadIdx.x < 256) cnt[threadIdx.x] = 0;
-  __syncthreads();
+  block_sync();
   // Bins of at most S2_TILE entries (every bin of a uniform input: 2^c/2^8 ... n/256 entries) are
   // held in registers between the counting and the scattering sweep: one pipelined read of the
   // bin, no second read.  Larger bins (skewed digits) stream twice.
@@ -523,7 +528,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sort2(const u32* __restrict__ co
       lds_rank(cnt, v & lo_mask, live);
     }
   }
-  __syncthreads();
+  block_sync();
   // exclusive scan of the NLO (<= 256) counts
   const int t = threadIdx.x;
   const u32 ct = (t < NLO) ? cnt[t] : 0u;
@@ -535,7 +540,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sort2(const u32* __restrict__ co
     if (lane >= o) incl += x;
   }
   if (lane == 63) wsum[t >> 6] = incl;
-  __syncthreads();
+  block_sync();
   u32 woff = 0;
   for (int k = 0; k < (t >> 6); k++) woff += wsum[k];
   const u32 excl = woff + incl - ct;
@@ -543,7 +548,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sort2(const u32* __restrict__ co
     hist[bucket0 + t] = ct;
     cur[t] = b0 + excl;
   }
-  __syncthreads();
+  block_sync();
   if (small) {
 #pragma unroll
     for (int k = 0; k < S2_PER; k++) {
@@ -553,7 +558,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sort2(const u32* __restrict__ co
       const u32 pos = lds_rank(cur, lo, live);
       if (live) stage[pos - b0] = vreg[k];
     }
-    __syncthreads();
+    block_sync();
     // sorted inside LDS; write out in order (coalesced)
     for (u32 j = threadIdx.x; j < b1 - b0; j += SORT_BLOCK) {
       const u32 v = stage[j];
@@ -587,7 +592,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_blocksum(const u32* __restr
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
-  __syncthreads();
+  block_sync();
   if (threadIdx.x == 0) {
     u32 t = 0;
     for (int k = 0; k < SCAN_BLOCK / 64; k++) t += sh[k];
@@ -599,23 +604,23 @@ __global__ void __launch_bounds__(1024) k_scan_top(u32* __restrict__ blocksum, i
   __shared__ u32 sh[1024];
   __shared__ u32 carry;
   if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
+  block_sync();
   for (int base = 0; base < nb; base += 1024) {
     const int i = base + threadIdx.x;
     const u32 v = (i < nb) ? blocksum[i] : 0u;
     sh[threadIdx.x] = v;
-    __syncthreads();
+    block_sync();
     for (int o = 1; o < 1024; o <<= 1) {
       const u32 t = (threadIdx.x >= (unsigned)o) ? sh[threadIdx.x - o] : 0u;
-      __syncthreads();
+      block_sync();
       sh[threadIdx.x] += t;
-      __syncthreads();
+      block_sync();
     }
     const u32 incl = sh[threadIdx.x];
     if (i < nb) blocksum[i] = carry + incl - v;
-    __syncthreads();
+    block_sync();
     if (threadIdx.x == 1023) carry += incl;
-    __syncthreads();
+    block_sync();
   }
   if (threadIdx.x == 0) *total = carry;
 }
@@ -640,7 +645,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_final(const u32* __restrict
     if (lane >= o) incl += t;
   }
   if (lane == 63) sh[threadIdx.x >> 6] = incl;
-  __syncthreads();
+  block_sync();
   u32 wave_off = 0;
   for (int k = 0; k < (int)(threadIdx.x >> 6); k++) wave_off += sh[k];
   u32 run = blocksum[blockIdx.x] + wave_off + incl - s;
@@ -797,7 +802,7 @@ k_segreduce_small(const u32* __restrict__ d_count, int n_in, int L, u32* __restr
     for (int t = threadIdx.x; t < lanes; t += blockDim.x)
       segreduce_lane<CV, false>(t, bi, nullptr, pi, d_count, n_in, L, buckets, bo, po);
     if (lanes == 1) break;
-    __syncthreads();  // (also orders the global writes of this level before the next level's reads)
+    block_sync();  // (also orders the global writes of this level before the next level's reads)
     n_in = 2 * lanes;
     u32* tb = bi; bi = bo; bo = tb;
     u32* tp = pi; pi = po; po = tp;
@@ -1022,7 +1027,7 @@ __device__ void write_normalised(const Jac<CV>& r, u32* out) {
 // declaring all 512 VGPRs; wave 0 works, the other three sleep until it is done.  The accumulation
 // kernel then loses 1 CU of 256 instead of 20 % of its time — experimental, see msm_var.hip.
 template <class CV, bool EXCLUSIVE>
-__global__ void __launch_bounds__(256) k_finalize(const u32* __restrict__ A_w, const u32* __restrict__ R_w, int m,
+__global__ void __launch_bounds__(EXCLUSIVE ? 256 : 64) k_finalize(const u32* __restrict__ A_w, const u32* __restrict__ R_w, int m,
                                                   int g, int W, int c, int sd, u32* __restrict__ out) {
   using IO = CurveIO<CV>;
   __shared__ volatile int done;
@@ -1033,7 +1038,7 @@ __global__ void __launch_bounds__(256) k_finalize(const u32* __restrict__ A_w, c
   }
   if (blockIdx.x != 0) return;
   if (threadIdx.x == 0) done = 0;
-  __syncthreads();
+  block_sync();
   if (threadIdx.x >= 64) {  // placeholder waves: hold the SIMD's registers, issue (almost) nothing
     while (!done) __builtin_amdgcn_s_sleep(64);
     return;

@@ -72,12 +72,22 @@ class VarMsmPipeline:
             self.levels_done.append(ev)
         self.count = 0
 
-    def __del__(self):
-        try:
+    def close(self):
+        """Destroy the ordering events (after the work that uses them has drained)."""
+        if self.levels_done:
             L = _lib.load()
             torch.cuda.synchronize()
             for ev in self.levels_done:
                 L.ozk_order_event_destroy(ev)
+            self.levels_done = []
+
+    def __del__(self):
+        # never call into HIP while the interpreter (and possibly the HIP runtime) is being torn down
+        import sys
+        if sys is None or sys.is_finalizing():
+            return
+        try:
+            self.close()
         except Exception:
             pass
 

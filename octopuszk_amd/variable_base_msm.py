@@ -115,6 +115,9 @@ class PreparedBases:
             self._h = ctypes.c_void_p()
 
     def __del__(self):
+        import sys
+        if sys is None or sys.is_finalizing():   # no HIP calls during interpreter teardown
+            return
         try:
             self.close()
         except Exception:

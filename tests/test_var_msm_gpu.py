@@ -192,6 +192,29 @@ def test_g1_max_chunk_linearity():
     assert whole != o.g1_out_le(o.G1.zero)
 
 
+def test_g1_2pow24_plain_windows_equal_two_glv_halves():
+    """BASELINE.json cfg-4 (N = 2^24).  One 2^24-pair call takes the plain 256-bit unsigned-window
+    plan (the GLV plan needs 2n <= 2^24 sortable points); its result must equal the sum of the two
+    2^23-pair halves, which take the GLV + signed-digit plan: two different code paths, same bytes."""
+    import torch
+    from octopuszk_amd import device as dev, lib
+    L = lib.load()
+    n = 1 << 24
+    assert L.ozk_var_msm_glv(n) == 0 and L.ozk_var_msm_glv(n // 2) == 1
+    bases, d_sc, _, whole = _device_msm(n, 11, 12)
+    h = n // 2
+    ws = dev.VarMsmWorkspace(h, 1)
+    parts = []
+    for k in range(2):
+        out = ws.run(bases[k * h * 96:(k + 1) * h * 96], d_sc[k * h * 32:(k + 1) * h * 32])
+        torch.cuda.synchronize()
+        parts.append(out.clone())
+    s = dev.points_sum(torch.cat(parts), 2, 1)
+    torch.cuda.synchronize()
+    assert bytes(s.cpu().numpy()) == whole
+    assert whole != o.g1_out_le(o.G1.zero)
+
+
 def test_pipelined_equals_serial():
     """Two MSMs in flight (head of k+1 overlapping tail of k) give the same bytes as serial calls."""
     import numpy as np
@@ -241,6 +264,34 @@ def test_g1_profiler_shaped_full_size():
     out = ws.run(d_bases, d_scalars)
     torch.cuda.synchronize()
     assert bytes(out.cpu().numpy()) == o.g1_out_le(o.G1.to_affine(o.G1.mul(base, sum(vals) % o.R)))
+
+
+def test_g1_profiler_shaped_repeatable():
+    """Regression for the big-bin sort (k_sortbig_*): the same skewed 2^20 MSM run 25 times over poisoned
+    workspaces must give the same, correct bytes every time.  A missing wait before a workgroup barrier
+    (curve.cuh block_sync) used to drop one wave's LDS counts in ~1 run out of 5."""
+    import numpy as np
+    import torch
+    from octopuszk_amd import device as dev
+    n = 1 << 20
+    rng = np.random.default_rng(10)
+    lows = rng.integers(0, 1 << 63, size=n, dtype=np.uint64)
+    neg = rng.integers(0, 2, size=n).astype(bool)
+    vals = [(o.R - int(v)) if ng else int(v) for v, ng in zip(lows, neg)]
+    sc = np.frombuffer(b"".join(v.to_bytes(32, "little") for v in vals), dtype=np.uint8).copy()
+    base = o.G1.to_affine(o.G1.mul(o.G1.one, 987654321))
+    bases = np.frombuffer(o.g1_to_wire(base) * n, dtype=np.uint8).copy()
+    d_bases, d_scalars = torch.from_numpy(bases).cuda(), torch.from_numpy(sc).cuda()
+    want = o.g1_out_le(o.G1.to_affine(o.G1.mul(base, sum(vals) % o.R)))
+    ws = dev.VarMsmWorkspace(n, 1)
+    bad = []
+    for rep in range(25):
+        ws.ws.fill_(0xFF if rep % 2 else 0)
+        out = ws.run(d_bases, d_scalars)
+        torch.cuda.synchronize()
+        if bytes(out.cpu().numpy()) != want:
+            bad.append(rep)
+    assert bad == []
 
 
 # ---- GLV endomorphism path (csrc/glv.cuh): scalars that stress the decomposition ----
