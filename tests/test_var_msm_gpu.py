@@ -266,6 +266,37 @@ def test_g1_profiler_shaped_full_size():
     assert bytes(out.cpu().numpy()) == o.g1_out_le(o.G1.to_affine(o.G1.mul(base, sum(vals) % o.R)))
 
 
+@pytest.mark.parametrize("kind", ["all_equal", "two_values", "all_one", "all_r_minus_1", "all_zero"])
+def test_g1_degenerate_scalar_distributions_full_size(kind):
+    """Every point in ONE bucket per window (all scalars equal): the extreme of the skew the big-bin sort
+    and the multi-level reduction exist for; 2^20 pairs, bases k_i G with known k_i."""
+    import numpy as np
+    import torch
+    from octopuszk_amd import device as dev
+    n = (1 << 20) + 4321          # not a power of two either
+    bases = dev.gen_g1_bases(n, seed=21)
+    ks = dev.gen_base_logs(n, 21)
+    c1 = 0x1234567890abcdef1234567890abcdef1234567890abcdef1234567890abcd % o.R
+    c2 = (o.R - 0xfedcba9876543210fedcba98765) % o.R
+    if kind == "all_equal":
+        vals = [c1] * n
+    elif kind == "two_values":
+        vals = [c1 if (i * 7919) % 3 else c2 for i in range(n)]
+    elif kind == "all_one":
+        vals = [1] * n
+    elif kind == "all_r_minus_1":
+        vals = [o.R - 1] * n
+    else:
+        vals = [0] * n
+    uniq = {v: np.frombuffer(v.to_bytes(32, "little"), dtype=np.uint8) for v in set(vals)}
+    sc = np.stack([uniq[v] for v in vals]).reshape(-1).copy()
+    ws = dev.VarMsmWorkspace(n, 1)
+    out = ws.run(bases, torch.from_numpy(sc).cuda())
+    torch.cuda.synchronize()
+    acc = sum(v * k for v, k in zip(vals, ks)) % o.R
+    assert bytes(out.cpu().numpy()) == o.g1_out_le(o.G1.to_affine(o.G1.mul(o.G1.one, acc)))
+
+
 def test_g1_profiler_shaped_repeatable():
     """Regression for the big-bin sort (k_sortbig_*): the same skewed 2^20 MSM run 25 times over poisoned
     workspaces must give the same, correct bytes every time.  A missing wait before a workgroup barrier
