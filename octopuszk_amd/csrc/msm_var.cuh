@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(256) k_convert_bases(const u32* __restrict__ w
 
 // ------------------------------------------------------------------ digits
 // digits[w*n + i] (u16): the c-bit digit of scalar i in window w.  One pass over the scalars.
-__global__ void __launch_bounds__(256) k_digits(const u32* __restrict__ scalars, int n, int c, int W,
+static __global__ void __launch_bounds__(256) k_digits(const u32* __restrict__ scalars, int n, int c, int W,
                                                 uint16_t* __restrict__ digits) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(256) k_digits(const u32* __restrict__ scalars,
 // n + i = |k2| of a 2n-point MSM with W = ceil(128 / c) windows.  Signed-digit plans XOR the sign of
 // the half scalar into every digit's sign; unsigned plans leave the signs in neg_flags for
 // k_convert_bases.
-__global__ void __launch_bounds__(256) k_digits_glv(const u32* __restrict__ scalars, int n, int c, int W, int sd,
+static __global__ void __launch_bounds__(256) k_digits_glv(const u32* __restrict__ scalars, int n, int c, int W, int sd,
                                                     uint16_t* __restrict__ digits, uint8_t* __restrict__ neg_flags) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -238,7 +238,7 @@ __device__ __forceinline__ u32 lds_rank(u32* cnt, u32 key, bool live) {
 }
 
 // C1[(w*NH + h)*nblk + blk] = number of non-zero digits with hi value h in this block's chunk
-__global__ void __launch_bounds__(SORT_BLOCK) k_sort1_count(const uint16_t* __restrict__ digits, int n, int lo_bits,
+static __global__ void __launch_bounds__(SORT_BLOCK) k_sort1_count(const uint16_t* __restrict__ digits, int n, int lo_bits,
                                                             int sd, int NH, int nblk, u32* __restrict__ C1) {
   extern __shared__ u32 cnt[];
   const int w = blockIdx.y, blk = blockIdx.x;
@@ -266,7 +266,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sort1_count(const uint16_t* __re
 // The chunk is first sorted by hi inside LDS and then written out in bin order: consecutive lanes
 // write consecutive words of a bin (runs of ~16 words per bin and block = one 64-byte request
 // instead of 16 four-byte ones; the scattered form was bound by the L2 request rate).
-__global__ void __launch_bounds__(SORT_BLOCK) k_sort1_scatter(const uint16_t* __restrict__ digits, int n, int lo_bits,
+static __global__ void __launch_bounds__(SORT_BLOCK) k_sort1_scatter(const uint16_t* __restrict__ digits, int n, int lo_bits,
                                                               int sd, int NH, int nblk, const u32* __restrict__ P1,
                                                               const u32* __restrict__ total, size_t nC1,
                                                               u32* __restrict__ coarse) {
@@ -346,7 +346,7 @@ struct BigBins {                        // device-resident work list
   u32 bin[SORTBIG_MAXBINS], b0[SORTBIG_MAXBINS], size[SORTBIG_MAXBINS], first_item[SORTBIG_MAXBINS];
 };
 
-__global__ void __launch_bounds__(256) k_sortbig_list(const u32* __restrict__ P1, const u32* __restrict__ total,
+static __global__ void __launch_bounds__(256) k_sortbig_list(const u32* __restrict__ P1, const u32* __restrict__ total,
                                                       int nblk, int nbins, u32 big_thresh,
                                                       BigBins* __restrict__ bb) {
   __shared__ u32 n_big, n_items;
@@ -391,7 +391,7 @@ __device__ __forceinline__ bool sortbig_item(const BigBins* bb, u32 item, u32& r
 }
 
 // T[item][lo] = count of lo in the item's chunk
-__global__ void __launch_bounds__(SORT_BLOCK) k_sortbig_count(const u32* __restrict__ coarse,
+static __global__ void __launch_bounds__(SORT_BLOCK) k_sortbig_count(const u32* __restrict__ coarse,
                                                               const BigBins* __restrict__ bb, u32 lo_mask,
                                                               u32* __restrict__ T) {
   __shared__ u32 cnt[256];
@@ -416,7 +416,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sortbig_count(const u32* __restr
 }
 
 // one block per big bin, lane = lo: bucket totals, bucket bases, per-item bases (in place in T)
-__global__ void __launch_bounds__(256) k_sortbig_scan(const BigBins* __restrict__ bb, u32* __restrict__ T, int c,
+static __global__ void __launch_bounds__(256) k_sortbig_scan(const BigBins* __restrict__ bb, u32* __restrict__ T, int c,
                                                       int lo_bits, int NH, u32* __restrict__ hist) {
   __shared__ u32 wsum[4];
   const u32 r = blockIdx.x;
@@ -449,7 +449,7 @@ __global__ void __launch_bounds__(256) k_sortbig_scan(const BigBins* __restrict_
   }
 }
 
-__global__ void __launch_bounds__(SORT_BLOCK) k_sortbig_scatter(const u32* __restrict__ coarse,
+static __global__ void __launch_bounds__(SORT_BLOCK) k_sortbig_scatter(const u32* __restrict__ coarse,
                                                                 const BigBins* __restrict__ bb,
                                                                 const u32* __restrict__ T, int c, int lo_bits,
                                                                 u32 sign_bit, int NH, u32* __restrict__ sidx,
@@ -483,7 +483,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sortbig_scatter(const u32* __res
 }
 
 // one block per coarse bin (w, h): finishes the sort inside the bin
-__global__ void __launch_bounds__(SORT_BLOCK) k_sort2(const u32* __restrict__ coarse, const u32* __restrict__ P1,
+static __global__ void __launch_bounds__(SORT_BLOCK) k_sort2(const u32* __restrict__ coarse, const u32* __restrict__ P1,
                                                       const u32* __restrict__ total, int c, int lo_bits, int NH,
                                                       u32 sign_bit, int nblk, int nbins, u32 big_thresh,
                                                       u32* __restrict__ hist, u32* __restrict__ sidx,
@@ -582,7 +582,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sort2(const u32* __restrict__ co
 // ------------------------------------------------------------------ exclusive scan (3 kernels)
 constexpr int SCAN_ITEMS = 16;   // per lane
 constexpr int SCAN_BLOCK = 256;  // lanes -> 4096 items per block
-__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_blocksum(const u32* __restrict__ in, int n,
+static __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_blocksum(const u32* __restrict__ in, int n,
                                                               u32* __restrict__ blocksum) {
   __shared__ u32 sh[SCAN_BLOCK / 64];
   const size_t base = (size_t)blockIdx.x * SCAN_BLOCK * SCAN_ITEMS + (size_t)threadIdx.x * SCAN_ITEMS;
@@ -600,7 +600,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_blocksum(const u32* __restr
   }
 }
 // single block: exclusive scan of nb block sums in place; total -> *total
-__global__ void __launch_bounds__(1024) k_scan_top(u32* __restrict__ blocksum, int nb, u32* __restrict__ total) {
+static __global__ void __launch_bounds__(1024) k_scan_top(u32* __restrict__ blocksum, int nb, u32* __restrict__ total) {
   __shared__ u32 sh[1024];
   __shared__ u32 carry;
   if (threadIdx.x == 0) carry = 0;
@@ -624,7 +624,7 @@ __global__ void __launch_bounds__(1024) k_scan_top(u32* __restrict__ blocksum, i
   }
   if (threadIdx.x == 0) *total = carry;
 }
-__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_final(const u32* __restrict__ in, int n,
+static __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_final(const u32* __restrict__ in, int n,
                                                            const u32* __restrict__ blocksum,
                                                            u32* __restrict__ out) {
   __shared__ u32 sh[SCAN_BLOCK / 64];

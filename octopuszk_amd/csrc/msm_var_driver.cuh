@@ -1,0 +1,589 @@
+// Variable-base MSM: host driver templates (plan, workspace layout, stage launchers, host-buffer and
+// prepared-bases paths), shared by the two translation units that instantiate them — msm_var.hip
+// (G1 + the C ABI) and msm_var_g2.hip (G2) — so that the two heavy instantiations compile in parallel.
+#pragma once
+#include <pthread.h>
+#include <stdlib.h>
+
+#include <vector>
+
+#ifndef OZK_WITH_G2
+#define OZK_WITH_G2 1
+#endif
+#include "msm_var.cuh"
+#include "ozk_common.h"
+#include "fq2.cuh"
+
+namespace ozk {
+
+// Optional per-launch timing of the dominant kernel (level-1 segmented reduce) with HIP
+// events recorded on the stream it is launched on; bench.py reads the average after its
+// timed region (roofline.achieved).
+struct ProfState {
+  bool on = false;
+  int count = 0;
+  static constexpr int MAXP = 512;
+  hipEvent_t e0[MAXP], e1[MAXP];
+  bool created = false;
+};
+inline ProfState g_prof;
+
+// GLV needs 2n <= 2^24 sortable points (24-bit index in the packed coarse words).
+constexpr int GLV_MAX_N = 1 << 23;
+
+static MsmPlan make_plan(int n) {
+  MsmPlan p;
+  p.n_in = n;
+  p.glv = env_int("OZK_MSM_GLV", 1) != 0 && n <= GLV_MAX_N;
+  p.n = p.glv ? 2 * n : n;
+  // Window size by cost model: bucket additions (points x windows) plus ~3.4 addition-equivalents
+  // per bucket for the window sums (two Jacobian additions of 16-18 multiplications against 10 for a
+  // mixed XYZZ addition).  A window count that leaves the top window nearly empty (c = 15 over 128
+  // bits: 9 windows, the ninth 7 bits wide) also piles thousands of entries into a few buckets and
+  // wakes the generic reduction levels — measured on G2 at 2^18: 8.1 ms with c = 15, the model's
+  // c = 16 avoids it.
+  const int sd_ok = p.glv && env_int("OZK_MSM_SIGNED", 1) != 0;
+  const int bits = p.glv ? 128 : 256;
+  int c = 4;
+  double best = 1e300;
+  for (int k = 4; k <= 16; k++) {
+    const double W = (double)((bits + k - 1) / k);
+    const double cost = (double)p.n * W + 3.4 * W * (double)(1u << (k - sd_ok));
+    if (cost < best) {
+      best = cost;
+      c = k;
+    }
+  }
+  c = env_int("OZK_MSM_C", c);
+  if (c < 1) c = 1;
+  if (c > 16) c = 16;
+  p.c = c;
+  p.sd = p.glv && c >= 2 && env_int("OZK_MSM_SIGNED", 1) != 0;
+  p.cb = c - p.sd;
+  p.W = ((p.glv ? 128 : 256) + c - 1) / c;
+  p.L1 = env_int("OZK_MSM_L1", 40);
+  p.LK = env_int("OZK_MSM_LK", 16);
+  if (p.L1 < 2) p.L1 = 2;
+  if (p.LK < 4) p.LK = 4;
+  int S = env_int("OZK_MSM_S", 4);
+  int sg = ilog2((uint32_t)(S < 2 ? 2 : S));
+  p.S = 1 << sg;
+  return p;
+}
+
+struct MsmLayout {
+  // all device pointers into the workspace
+  u32* aff;
+  u32 *hist, *C1, *P1, *blocksum, *total;  // total[0] = sorted entries, total[1] = live partial slots
+  uint16_t* digits;
+  uint8_t* neg_flags;  // GLV: sign of each half scalar
+  u32 *coarse, *sidx, *sbid;
+  BigBins* bigbins;
+  u32* bigT;
+  size_t big_items_max;
+  int lo_bits, NH, nblk;
+  size_t nC1;
+  u32* buckets;   // tail region: bucket records, read by the first window-sum level
+  u32* hist_t;    // tail region: copy of the bucket counts (the sorted set is reused by the next head)
+  u32 *slot_bid[2], *slot_pts[2], *slot_bid2;
+  u32 *wA[2], *wR[2];
+  size_t bytes;
+  size_t cap;   // n * W sorted entries at most
+  size_t NB;    // W << c buckets
+  size_t slots0, slots1;
+  size_t m1;    // wsum elements per window after the first level
+};
+
+// Three regions, so that a caller can pipeline three stages of consecutive MSMs:
+//   sorted set   : affine bases, bucket counts, sorted (index, bucket id) arrays, counters —
+//                  the hand-off from the SORT stage to the ACCUMULATE stage (double-buffer it)
+//   sort scratch : digits, per-block counts and their scan, coarse bins, big-bin work list
+//   accum scratch: bucket records and partial slots
+struct RegionBytes {
+  size_t sorted, sort_ws, accum_ws;
+};
+template <class CV>
+MsmLayout make_layout3(const MsmPlan& p, void* sorted, void* sort_ws, void* accum_ws, RegionBytes* rb,
+                              const void* prepared = nullptr) {
+  using IO = CurveIO<CV>;
+  MsmLayout L;
+  L.cap = (size_t)p.n * p.W;
+  L.NB = (size_t)p.W << p.cb;
+  const int lo_max = p.sd ? 7 : 8;  // signed: bit 7 of the packed coarse word carries the sign
+  L.lo_bits = p.cb < lo_max ? p.cb : lo_max;
+  L.NH = 1 << (p.cb - L.lo_bits);
+  L.nblk = (p.n + SORT_CHUNK - 1) / SORT_CHUNK;
+  L.nC1 = (size_t)p.W * L.NH * L.nblk;
+  Bump a(sorted, ~(size_t)0);
+  L.aff = a.take<u32>((size_t)p.n * IO::AFF_WORDS);
+  if (prepared) L.aff = (u32*)prepared;  // affine records kept across MSMs (ozk_var_msm_prepare_dev)
+  L.hist = a.take<u32>(L.NB);
+  L.total = a.take<u32>(4);
+  L.sidx = a.take<u32>(L.cap);
+  L.sbid = a.take<u32>(L.cap + 1);
+  a.take<u32>(64);
+  Bump b(sort_ws, ~(size_t)0);
+  L.C1 = b.take<u32>(L.nC1);
+  L.P1 = b.take<u32>(L.nC1);
+  L.blocksum = b.take<u32>(L.nC1 / (SCAN_BLOCK * SCAN_ITEMS) + 2);
+  L.digits = b.take<uint16_t>(L.cap);
+  L.neg_flags = b.take<uint8_t>((size_t)p.n);
+  L.coarse = b.take<u32>(L.cap);
+  L.bigbins = b.take<BigBins>(1);
+  L.big_items_max = L.cap / SORTBIG_CHUNK + SORTBIG_MAXBINS + 1;
+  L.bigT = b.take<u32>(L.big_items_max * 256);
+  b.take<u32>(64);
+  Bump c(accum_ws, ~(size_t)0);
+  const size_t T1 = (L.cap + p.L1 - 1) / p.L1;
+  L.slots0 = 2 * T1;
+  const size_t T2 = (L.slots0 + p.LK - 1) / p.LK;
+  L.slots1 = 2 * T2;
+  L.slot_bid[0] = c.take<u32>(L.slots0);
+  L.slot_pts[0] = c.take<u32>(L.slots0 * IO::REC_WORDS);
+  L.slot_bid2 = c.take<u32>(L.slots0);
+  L.slot_bid[1] = c.take<u32>(L.slots1);
+  L.slot_pts[1] = c.take<u32>(L.slots1 * IO::REC_WORDS);
+  c.take<u32>(64);
+  L.m1 = (((size_t)1 << p.cb) + p.S - 1) / p.S;
+  if (rb) {
+    rb->sorted = (a.off + 255) & ~(size_t)255;
+    rb->sort_ws = (b.off + 255) & ~(size_t)255;
+    rb->accum_ws = (c.off + 255) & ~(size_t)255;
+  }
+  L.bytes = a.off + b.off + c.off;
+  return L;
+}
+template <class CV>
+RegionBytes region_bytes(int n) {
+  RegionBytes rb;
+  make_layout3<CV>(make_plan(n), nullptr, nullptr, nullptr, &rb);
+  return rb;
+}
+
+// The "tail" buffers (bucket records + counts, window-sum elements): the only state the
+// latency-bound tail phase reads.
+// They live outside the main workspace so that a caller can keep several MSMs in flight: the
+// head phase of the next MSM may reuse the whole main workspace while this MSM's tail still
+// runs on another stream.
+template <class CV>
+size_t tail_layout(const MsmPlan& p, MsmLayout& L, void* tail, size_t tail_bytes) {
+  using IO = CurveIO<CV>;
+  Bump b(tail, tail_bytes);
+  L.NB = (size_t)p.W << p.cb;
+  L.m1 = (((size_t)1 << p.cb) + p.S - 1) / p.S;
+  L.buckets = b.take<u32>(L.NB * IO::REC_WORDS);
+  L.hist_t = b.take<u32>(L.NB);
+  for (int k = 0; k < 2; k++) {
+    L.wA[k] = b.take<u32>((size_t)p.W * L.m1 * IO::JAC_WORDS);
+    L.wR[k] = b.take<u32>((size_t)p.W * L.m1 * IO::JAC_WORDS);
+  }
+  b.take<u32>(64);
+  return b.off;
+}
+
+// First window-sum level.  Fused form (default): a lane sums S = 4 buckets, its wave combines the 64
+// lane results in registers -> W * 2^c / 256 elements.  Everything after the bucket accumulation is
+// multiplier-issue work spread over few waves, so WHERE it runs matters more than how deep it is
+// (measured at 2^20, two MSMs in flight, Mscalar-mul/s / single-MSM ms):
+//     unfused S=16, closing the head phase                      444-447 / 3.40-3.44
+//     fused S=4, opening the tail phase, no issue priority      461-465 / 3.48-3.64   <- default
+//     fused S=16 / unfused S=8 in the tail, with or without priority: 372-420 (their 512-1024 waves
+//     sit on the same SIMDs as the next MSM's bucket accumulation and stretch it 1.35 -> 1.5-1.9 ms)
+static bool wsum0_in_tail() { return env_int("OZK_MSM_WSUM0_IN_TAIL", 1) != 0; }
+static bool wsum_fused() { return env_int("OZK_MSM_WSUM_FUSED", 1) != 0; }
+// elements per window the first level leaves, and the g (log2 of buckets per element) they carry
+static void first_level_shape(const MsmPlan& p, int* m_out, int* g_out) {
+  const int m_in = 1 << p.cb;
+  const int nseg = (m_in + p.S - 1) / p.S;
+  const int sg = ilog2((uint32_t)p.S);
+  if (wsum_fused()) {
+    *m_out = (nseg + 63) / 64;
+    *g_out = sg + 6;
+  } else {
+    *m_out = nseg;
+    *g_out = sg;
+  }
+}
+template <class CV>
+void launch_wsum0(const MsmPlan& p, const MsmLayout& L, hipStream_t st, int prio) {
+  const int TB = 256;
+  const int m_in = 1 << p.cb;
+  int m_out, g;
+  first_level_shape(p, &m_out, &g);
+  const int tot = m_out * p.W;
+  if (wsum_fused())
+    hipLaunchKernelGGL((k_wsum_fused<CV>), dim3(tot), dim3(64), 0, st, L.buckets, L.hist_t, m_in, p.S,
+                       ilog2((uint32_t)p.S), L.wA[0], L.wR[0], m_out, p.W, prio);
+  else
+    hipLaunchKernelGGL((k_wsum<CV, true>), dim3((tot + TB - 1) / TB), dim3(TB), 0, st, (const u32*)nullptr,
+                       L.buckets, L.hist_t, m_in, p.S, 0, L.wA[0], L.wR[0], m_out, p.W, prio);
+}
+
+// SORT stage: bases -> affine Montgomery, digits, two-level counting sort.  Memory / LDS-bound;
+// leaves the "sorted set".
+template <class CV>
+int var_msm_sort(const void* d_bases, const void* d_scalars, int n, void* sorted, size_t sorted_bytes,
+                        void* sort_ws, size_t sort_ws_bytes, hipStream_t st, hipEvent_t order_ev = nullptr,
+                        const void* prepared = nullptr) {
+  const MsmPlan p = make_plan(n);
+  if (prepared && p.glv && !p.sd) return fail(OZK_E_INVALID, "prepared bases need the signed-digit plan");
+  RegionBytes rb;
+  const MsmLayout L = make_layout3<CV>(p, sorted, sort_ws, nullptr, &rb, prepared);
+  if (rb.sorted > sorted_bytes || rb.sort_ws > sort_ws_bytes)
+    return fail(OZK_E_INVALID, "sort buffers too small: need %zu + %zu bytes, got %zu + %zu", rb.sorted, rb.sort_ws,
+                sorted_bytes, sort_ws_bytes);
+  const int TB = 256;
+  const u32* bases = (const u32*)d_bases;
+  const u32* scalars = (const u32*)d_scalars;
+  const int n_in = p.n_in;
+  n = p.n;  // from here on: the points the pipeline sorts (2 * n_in with GLV)
+  OZK_HIP(hipMemsetAsync(L.total, 0, 4 * sizeof(u32), st));
+  if (p.glv) {
+    hipLaunchKernelGGL(k_digits_glv, dim3((n_in + TB - 1) / TB), dim3(TB), 0, st, scalars, n_in, p.c, p.W, p.sd,
+                       L.digits, L.neg_flags);
+    if (!prepared)
+      hipLaunchKernelGGL((k_convert_bases<CV>), dim3((n_in + TB - 1) / TB), dim3(TB), 0, st, bases, L.aff, n_in, 1,
+                         p.sd ? (const uint8_t*)nullptr : (const uint8_t*)L.neg_flags);
+  } else {
+    if (!prepared)
+      hipLaunchKernelGGL((k_convert_bases<CV>), dim3((n_in + TB - 1) / TB), dim3(TB), 0, st, bases, L.aff, n_in, 0,
+                         (const uint8_t*)nullptr);
+    hipLaunchKernelGGL(k_digits, dim3((n_in + TB - 1) / TB), dim3(TB), 0, st, scalars, n_in, p.c, p.W, L.digits);
+  }
+  // two-level counting sort by (window, digit): per-block LDS counts of the hi part, one global
+  // exclusive scan, coarse scatter, then one block per coarse bin finishes by the lo part
+  const size_t lds1 = (size_t)L.NH * sizeof(u32);
+  hipLaunchKernelGGL(k_sort1_count, dim3(L.nblk, p.W), dim3(SORT_BLOCK), lds1, st, L.digits, n, L.lo_bits, p.sd,
+                     L.NH, L.nblk, L.C1);
+  const int items = SCAN_BLOCK * SCAN_ITEMS;
+  const int nb = (int)((L.nC1 + items - 1) / items);
+  hipLaunchKernelGGL(k_scan_blocksum, dim3(nb), dim3(SCAN_BLOCK), 0, st, L.C1, (int)L.nC1, L.blocksum);
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, L.blocksum, nb, L.total);
+  hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_BLOCK), 0, st, L.C1, (int)L.nC1, L.blocksum, L.P1);
+  const size_t lds_sc = ((size_t)2 * L.NH + 2 * SORT_CHUNK) * sizeof(u32);
+  hipLaunchKernelGGL(k_sort1_scatter, dim3(L.nblk, p.W), dim3(SORT_BLOCK), lds_sc, st, L.digits, n, L.lo_bits,
+                     p.sd, L.NH, L.nblk, L.P1, L.total, L.nC1, L.coarse);
+  const int nbins = p.W * L.NH;
+  const u32 sign_bit = p.sd ? 0x80u : 0u;
+  const u32 big_thresh = (u32)(n / 64) > SORT_BIG ? (u32)(n / 64) : SORT_BIG;
+  hipLaunchKernelGGL(k_sort2, dim3(nbins), dim3(SORT_BLOCK), 0, st, L.coarse, L.P1, L.total, p.cb, L.lo_bits, L.NH,
+                     sign_bit, L.nblk, nbins, big_thresh, L.hist, L.sidx, L.sbid);
+  // Ordering hint for pipelined MSMs (see ozk_var_msm_tail_ordered_dev): everything up to here may
+  // overlap the previous MSM's window-sum levels; the bucket accumulation that follows fills every
+  // SIMD's register file, so the previous MSM's single-wave Horner kernel has to be resident first.
+  if (order_ev) OZK_HIP(hipStreamWaitEvent(st, order_ev, 0));
+  // bins above the threshold (skewed digits), split over a fixed grid; no-ops otherwise
+  hipLaunchKernelGGL(k_sortbig_list, dim3(1), dim3(256), 0, st, L.P1, L.total, L.nblk, nbins, big_thresh, L.bigbins);
+  hipLaunchKernelGGL(k_sortbig_count, dim3(1024), dim3(SORT_BLOCK), 0, st, L.coarse, L.bigbins,
+                     (1u << L.lo_bits) - 1u, L.bigT);
+  hipLaunchKernelGGL(k_sortbig_scan, dim3(SORTBIG_MAXBINS), dim3(256), 0, st, L.bigbins, L.bigT, p.cb, L.lo_bits, L.NH,
+                     L.hist);
+  hipLaunchKernelGGL(k_sortbig_scatter, dim3(1024), dim3(SORT_BLOCK), 0, st, L.coarse, L.bigbins, L.bigT, p.cb,
+                     L.lo_bits, sign_bit, L.NH, L.sidx, L.sbid);
+  OZK_HIP(hipGetLastError());
+  return OZK_OK;
+}
+
+// ACCUMULATE stage: bucket accumulation, run merge, generic levels, first window-sum level.
+// Vector-ALU-bound.  Reads the sorted set, leaves W * 2^c / S window-sum elements in the tail buffers.
+template <class CV>
+int var_msm_accum(int n, void* sorted, size_t sorted_bytes, void* accum_ws, size_t accum_ws_bytes, void* tail,
+                         size_t tail_bytes, hipStream_t st, const void* prepared = nullptr) {
+  using CT = CV;  // (an out-of-line-multiplication variant for the tails measured 40 % slower)
+  const MsmPlan p = make_plan(n);
+  RegionBytes rb;
+  MsmLayout L = make_layout3<CV>(p, sorted, nullptr, accum_ws, &rb, prepared);
+  if (rb.sorted > sorted_bytes || rb.accum_ws > accum_ws_bytes)
+    return fail(OZK_E_INVALID, "accumulate buffers too small: need %zu + %zu bytes, got %zu + %zu", rb.sorted,
+                rb.accum_ws, sorted_bytes, accum_ws_bytes);
+  const size_t tneed = tail_layout<CV>(p, L, tail, tail_bytes);
+  if (tneed > tail_bytes) return fail(OZK_E_INVALID, "tail buffer too small: need %zu bytes, got %zu", tneed, tail_bytes);
+  const int TB = 256;
+  // level 1 over the sorted entries
+  size_t lanes = (L.cap + p.L1 - 1) / p.L1;
+  const bool prof = g_prof.on && g_prof.created && g_prof.count < ProfState::MAXP;
+  if (prof) hipEventRecord(g_prof.e0[g_prof.count], st);
+  hipLaunchKernelGGL((k_segreduce<CV, true>), dim3((unsigned)((lanes + TB - 1) / TB)), dim3(TB), 0, st,
+                     L.sbid, L.sidx, L.aff, L.total, 0, p.L1, L.buckets, L.slot_bid[0], L.slot_pts[0],
+                     (int)lanes);
+  if (prof) hipEventRecord(g_prof.e1[g_prof.count++], st);
+  // run merge: completes every bucket cut into at most RUN_MAX pieces; counts the surviving slots
+  size_t n_in = 2 * lanes;
+  hipLaunchKernelGGL((k_runmerge<CT>), dim3((unsigned)((lanes + TB - 1) / TB)), dim3(TB), 0, st, L.slot_bid[0],
+                     L.slot_pts[0], (int)n_in, L.buckets, L.slot_bid2, L.total + 1);
+  // levels >= 2 over the surviving partial slots, ping-pong, until a single lane has seen everything
+  // (they return at once when nothing survived)
+  int cur = 0;
+  bool first_generic = true;
+  const int small_lanes = env_int("OZK_MSM_SMALL_LEVEL_LANES", 1024);
+  while (true) {
+    lanes = (n_in + p.LK - 1) / p.LK;
+    if (!first_generic && (int)lanes <= small_lanes) {  // the remaining levels in one single-block launch
+      hipLaunchKernelGGL((k_segreduce_small<CT>), dim3(1), dim3(TB), 0, st, L.total + 1, (int)n_in, p.LK, L.buckets,
+                         L.slot_bid[cur], L.slot_pts[cur], L.slot_bid[cur ^ 1], L.slot_pts[cur ^ 1]);
+      break;
+    }
+    hipLaunchKernelGGL((k_segreduce<CT, false>), dim3((unsigned)((lanes + TB - 1) / TB)), dim3(TB), 0, st,
+                       first_generic ? L.slot_bid2 : L.slot_bid[cur], (const u32*)nullptr, L.slot_pts[cur],
+                       L.total + 1, (int)n_in, p.LK, L.buckets, L.slot_bid[cur ^ 1], L.slot_pts[cur ^ 1], (int)lanes);
+    first_generic = false;
+    if (lanes == 1) break;
+    n_in = 2 * lanes;
+    cur ^= 1;
+  }
+  // the tail needs the bucket counts after the next head has reused the sorted set
+  OZK_HIP(hipMemcpyAsync(L.hist_t, L.hist, L.NB * sizeof(u32), hipMemcpyDeviceToDevice, st));
+  if (!wsum0_in_tail()) launch_wsum0<CV>(p, L, st, 0);
+  OZK_HIP(hipGetLastError());
+  return OZK_OK;
+}
+
+// Head = SORT + ACCUMULATE on one stream, the three regions carved from one workspace.
+template <class CV>
+int var_msm_head(const void* d_bases, const void* d_scalars, int n, void* ws, size_t ws_bytes, void* tail,
+                        size_t tail_bytes, hipStream_t st, hipEvent_t order_ev = nullptr,
+                        const void* prepared = nullptr) {
+  const RegionBytes rb = region_bytes<CV>(n);
+  if (rb.sorted + rb.sort_ws + rb.accum_ws > ws_bytes)
+    return fail(OZK_E_INVALID, "workspace too small: need %zu bytes, got %zu", rb.sorted + rb.sort_ws + rb.accum_ws,
+                ws_bytes);
+  uint8_t* w = (uint8_t*)ws;
+  int rc = var_msm_sort<CV>(d_bases, d_scalars, n, w, rb.sorted, w + rb.sorted, rb.sort_ws, st, order_ev, prepared);
+  if (rc) return rc;
+  return var_msm_accum<CV>(n, w, rb.sorted, w + rb.sorted + rb.sort_ws, rb.accum_ws, tail, tail_bytes, st, prepared);
+}
+
+// Tail phase: the latency-bound remainder (wave-cooperative window-sum levels, Horner over the
+// windows, affine normalisation).  Reads only the tail buffers; writes the wire-out result.
+template <class CV>
+int var_msm_tail(int n, void* tail, size_t tail_bytes, void* d_out, hipStream_t st,
+                        hipEvent_t order_ev = nullptr) {
+  using CT = CV;
+  const MsmPlan p = make_plan(n);
+  MsmLayout L;
+  L.m1 = (((size_t)1 << p.cb) + p.S - 1) / p.S;
+  const size_t tneed = tail_layout<CV>(p, L, tail, tail_bytes);
+  if (tneed > tail_bytes) return fail(OZK_E_INVALID, "tail buffer too small: need %zu bytes, got %zu", tneed, tail_bytes);
+  if (wsum0_in_tail()) launch_wsum0<CV>(p, L, st, env_int("OZK_MSM_WSUM0_PRIO", 0));
+  int m_in, g, k = 0;
+  first_level_shape(p, &m_in, &g);
+  const int TB = 256;
+  const int sg = ilog2((uint32_t)p.S);
+  // Optional serial S-per-lane levels first (3 additions per element instead of the wave form's
+  // 13, but 24 dependent additions deep).  Measured at 2^20: 0.17 ms less single-MSM latency, but
+  // 13 % LESS throughput with two MSMs in flight (its 256 long-running waves sit beside the next
+  // MSM's bucket accumulation), so the default is wave-cooperative levels only.
+  const int serial_above = env_int("OZK_MSM_TAIL_SERIAL_ABOVE", 1 << 30);
+  while (m_in > serial_above) {
+    const int m_out = (m_in + p.S - 1) / p.S;
+    const int tot = m_out * p.W;
+    hipLaunchKernelGGL((k_wsum<CT, false>), dim3((tot + TB - 1) / TB), dim3(TB), 0, st, L.wA[k], L.wR[k],
+                       (const u32*)nullptr, m_in, p.S, g, L.wA[k ^ 1], L.wR[k ^ 1], m_out, p.W, 1);
+    m_in = m_out;
+    g += sg;
+    k ^= 1;
+  }
+  // wave-cooperative levels until a handful of elements per window is left; k_finalize finishes those
+  int fin_max = env_int("OZK_MSM_FIN_MAX", 4);
+  if (fin_max < 1) fin_max = 1;
+  if (fin_max > 16) fin_max = 16;
+  while (m_in > fin_max) {
+    const int m_out = (m_in + 63) / 64;
+    const int tot = m_out * p.W;
+    hipLaunchKernelGGL((k_wsum_wave<CT>), dim3(tot), dim3(64), 0, st, L.wA[k], L.wR[k], m_in, g, L.wA[k ^ 1],
+                       L.wR[k ^ 1], m_out, p.W);
+    m_in = m_out;
+    g += 6;
+    k ^= 1;
+  }
+  if (order_ev) OZK_HIP(hipEventRecord(order_ev, st));  // the multi-wave levels are done
+  // One wave (Horner is serial).  EXPERIMENTAL (off): with OZK_FINALIZE_EXCLUSIVE=1 the kernel runs four
+  // waves that declare the whole register file of a CU so that no bucket-accumulation wave shares its
+  // SIMDs: +9 % pipelined throughput when measured, but the process aborted reproducibly when ~60 HIP
+  // streams had been created and destroyed before it (suspected: mid-wave preemption of 512-register
+  // waves under queue oversubscription), so it is not the default.
+  if (env_int("OZK_FINALIZE_EXCLUSIVE", 0))
+    hipLaunchKernelGGL((k_finalize<CT, true>), dim3(1), dim3(256), 0, st, L.wA[k], L.wR[k], m_in, g, p.W, p.c,
+                       p.sd, (u32*)d_out);
+  else
+    hipLaunchKernelGGL((k_finalize<CT, false>), dim3(1), dim3(64), 0, st, L.wA[k], L.wR[k], m_in, g, p.W, p.c,
+                       p.sd, (u32*)d_out);
+  OZK_HIP(hipGetLastError());
+  return OZK_OK;
+}
+
+template <class CV>
+size_t var_msm_tail_bytes(int n) {
+  const MsmPlan p = make_plan(n);
+  MsmLayout L;
+  L.m1 = (((size_t)1 << p.cb) + p.S - 1) / p.S;
+  return tail_layout<CV>(p, L, nullptr, 0);
+}
+
+// head + tail on one stream, the tail buffers carved from the end of the workspace
+template <class CV>
+int var_msm_dev(const void* d_bases, const void* d_scalars, int n, void* d_out, void* ws,
+                       size_t ws_bytes, hipStream_t st, const void* prepared = nullptr) {
+  const RegionBytes rb0 = region_bytes<CV>(n);
+  const size_t main_bytes = rb0.sorted + rb0.sort_ws + rb0.accum_ws;
+  const size_t tb = var_msm_tail_bytes<CV>(n);
+  if (main_bytes + tb > ws_bytes)
+    return fail(OZK_E_INVALID, "workspace too small: need %zu bytes, got %zu", main_bytes + tb, ws_bytes);
+  uint8_t* tail = (uint8_t*)ws + main_bytes;
+  int rc = var_msm_head<CV>(d_bases, d_scalars, n, ws, main_bytes, tail, tb, st, nullptr, prepared);
+  if (rc) return rc;
+  return var_msm_tail<CV>(n, tail, tb, d_out, st);
+}
+
+template <class CV>
+size_t var_msm_head_ws_bytes(int n) {
+  const RegionBytes rb = region_bytes<CV>(n);
+  return rb.sorted + rb.sort_ws + rb.accum_ws;
+}
+template <class CV>
+size_t var_msm_ws_bytes(int n) {
+  return var_msm_head_ws_bytes<CV>(n) + var_msm_tail_bytes<CV>(n);
+}
+
+// host-buffer variant: H2D, run, D2H.  Buffers are per call (re-entrant; callers are
+// concurrent Spark task threads in the reference, SURVEY.md §8b "Threading").
+template <class CV>
+int var_msm_host(const uint8_t* bases, const uint8_t* scalars, int n, int task_id, uint8_t* out) {
+  using IO = CurveIO<CV>;
+  int rc = select_device(task_id);
+  if (rc) return rc;
+  const size_t base_bytes = (size_t)n * IO::WIRE_JAC_WORDS * 4, sc_bytes = (size_t)n * 32;
+  const size_t out_bytes = (size_t)IO::WIRE_JAC_WORDS * 8;
+  const size_t ws_bytes = var_msm_ws_bytes<CV>(n);
+  uint8_t* d = nullptr;
+  hipStream_t st = nullptr;
+  OZK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  hipError_t e = hipMalloc((void**)&d, base_bytes + sc_bytes + out_bytes + ws_bytes + 1024);
+  if (e != hipSuccess) {
+    hipStreamDestroy(st);
+    return fail(OZK_E_NOMEM, "hipMalloc(%zu) failed: %s", base_bytes + sc_bytes + ws_bytes, hipGetErrorString(e));
+  }
+  uint8_t* d_bases = d;
+  uint8_t* d_sc = d_bases + ((base_bytes + 255) & ~(size_t)255);
+  uint8_t* d_out = d_sc + ((sc_bytes + 255) & ~(size_t)255);
+  uint8_t* d_ws = d_out + 256 * ((out_bytes + 255) / 256);
+  rc = OZK_OK;
+  do {
+    if ((e = hipMemcpyAsync(d_bases, bases, base_bytes, hipMemcpyHostToDevice, st)) != hipSuccess) break;
+    if ((e = hipMemcpyAsync(d_sc, scalars, sc_bytes, hipMemcpyHostToDevice, st)) != hipSuccess) break;
+    rc = var_msm_dev<CV>(d_bases, d_sc, n, d_out, d_ws, ws_bytes, st);
+    if (rc) break;
+    if ((e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, st)) != hipSuccess) break;
+    e = hipStreamSynchronize(st);
+  } while (0);
+  hipFree(d);
+  hipStreamDestroy(st);
+  if (rc) return rc;
+  if (e != hipSuccess) return fail(OZK_E_NO_DEVICE, "HIP failure in var_msm_host: %s", hipGetErrorString(e));
+  return OZK_OK;
+}
+
+// ---- prepared bases: the affine Montgomery records (GLV: both halves) of a base
+// array, kept in HBM across MSMs.  A Groth16 proving key is fixed; the reference re-marshals and
+// re-uploads it for every proof (VariableBaseMSM.java:224-227).
+template <class CV>
+size_t prepared_bytes(int n) {
+  const MsmPlan p = make_plan(n);
+  return (((size_t)p.n * CurveIO<CV>::AFF_WORDS * sizeof(u32)) + 255) & ~(size_t)255;
+}
+template <class CV>
+int var_msm_prepare(const void* d_bases, int n, void* d_prepared, size_t bytes, hipStream_t st) {
+  const MsmPlan p = make_plan(n);
+  if (p.glv && !p.sd) return fail(OZK_E_INVALID, "prepared bases need the signed-digit plan");
+  if (bytes < prepared_bytes<CV>(n)) return fail(OZK_E_INVALID, "prepared buffer too small");
+  hipLaunchKernelGGL((k_convert_bases<CV>), dim3((n + 255) / 256), dim3(256), 0, st, (const u32*)d_bases,
+                     (u32*)d_prepared, n, p.glv, (const uint8_t*)nullptr);
+  OZK_HIP(hipGetLastError());
+  return OZK_OK;
+}
+
+// Host-side handle: prepared bases + everything an MSM over them needs, allocated once.
+struct BasesHandle {
+  int device, n, type;
+  hipStream_t st;
+  uint8_t *d_prepared, *d_scalars, *d_out, *d_ws;
+  size_t ws_bytes;
+  pthread_mutex_t mu;
+};
+
+template <class CV>
+int bases_create(const uint8_t* bases, int n, int type, int task_id, BasesHandle** out) {
+  using IO = CurveIO<CV>;
+  int rc = select_device(task_id);
+  if (rc) return rc;
+  BasesHandle* h = (BasesHandle*)calloc(1, sizeof(BasesHandle));
+  if (!h) return fail(OZK_E_NOMEM, "out of host memory");
+  hipGetDevice(&h->device);
+  h->n = n;
+  h->type = type;
+  pthread_mutex_init(&h->mu, nullptr);
+  const size_t wire = (size_t)n * IO::WIRE_JAC_WORDS * 4, pb = prepared_bytes<CV>(n);
+  h->ws_bytes = var_msm_ws_bytes<CV>(n);
+  hipError_t e = hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking);
+  uint8_t* d_wire = nullptr;
+  if (e == hipSuccess) e = hipMalloc((void**)&h->d_prepared, pb);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->d_scalars, (size_t)n * 32 + 256);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->d_out, 1024);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->d_ws, h->ws_bytes);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_wire, wire);
+  rc = OZK_OK;
+  if (e == hipSuccess) e = hipMemcpyAsync(d_wire, bases, wire, hipMemcpyHostToDevice, h->st);
+  if (e == hipSuccess) rc = var_msm_prepare<CV>(d_wire, n, h->d_prepared, pb, h->st);
+  if (e == hipSuccess && !rc) e = hipStreamSynchronize(h->st);
+  if (d_wire) hipFree(d_wire);
+  if (e != hipSuccess || rc) {
+    if (h->d_prepared) hipFree(h->d_prepared);
+    if (h->d_scalars) hipFree(h->d_scalars);
+    if (h->d_out) hipFree(h->d_out);
+    if (h->d_ws) hipFree(h->d_ws);
+    if (h->st) hipStreamDestroy(h->st);
+    free(h);
+    if (rc) return rc;
+    return fail(OZK_E_NOMEM, "HIP failure while preparing bases: %s", hipGetErrorString(e));
+  }
+  *out = h;
+  return OZK_OK;
+}
+
+template <class CV>
+int bases_msm(BasesHandle* h, const uint8_t* scalars, uint8_t* out) {
+  const size_t out_bytes = (size_t)CurveIO<CV>::WIRE_JAC_WORDS * 8;
+  pthread_mutex_lock(&h->mu);
+  int rc = OZK_OK;
+  hipError_t e = hipSetDevice(h->device);
+  do {
+    if (e != hipSuccess) break;
+    if ((e = hipMemcpyAsync(h->d_scalars, scalars, (size_t)h->n * 32, hipMemcpyHostToDevice, h->st)) != hipSuccess) break;
+    rc = var_msm_dev<CV>(nullptr, h->d_scalars, h->n, h->d_out, h->d_ws, h->ws_bytes, h->st, h->d_prepared);
+    if (rc) break;
+    if ((e = hipMemcpyAsync(out, h->d_out, out_bytes, hipMemcpyDeviceToHost, h->st)) != hipSuccess) break;
+    e = hipStreamSynchronize(h->st);
+  } while (0);
+  pthread_mutex_unlock(&h->mu);
+  if (rc) return rc;
+  if (e != hipSuccess) return fail(OZK_E_NO_DEVICE, "HIP failure in MSM over prepared bases: %s", hipGetErrorString(e));
+  return OZK_OK;
+}
+
+}  // namespace ozk
+
+// the G2 instantiations live in msm_var_g2.hip
+#define OZK_G2_DRIVER_INSTANCES(PREFIX)                                                                              \
+  PREFIX template int ozk::var_msm_sort<ozk::G2Cfg>(const void*, const void*, int, void*, size_t, void*, size_t,    \
+                                                    hipStream_t, hipEvent_t, const void*);                          \
+  PREFIX template int ozk::var_msm_accum<ozk::G2Cfg>(int, void*, size_t, void*, size_t, void*, size_t, hipStream_t,  \
+                                                     const void*);                                                   \
+  PREFIX template int ozk::var_msm_head<ozk::G2Cfg>(const void*, const void*, int, void*, size_t, void*, size_t,     \
+                                                    hipStream_t, hipEvent_t, const void*);                          \
+  PREFIX template int ozk::var_msm_tail<ozk::G2Cfg>(int, void*, size_t, void*, hipStream_t, hipEvent_t);             \
+  PREFIX template int ozk::var_msm_dev<ozk::G2Cfg>(const void*, const void*, int, void*, void*, size_t, hipStream_t,  \
+                                                   const void*);                                                     \
+  PREFIX template int ozk::var_msm_host<ozk::G2Cfg>(const uint8_t*, const uint8_t*, int, int, uint8_t*);             \
+  PREFIX template int ozk::var_msm_prepare<ozk::G2Cfg>(const void*, int, void*, size_t, hipStream_t);                \
+  PREFIX template int ozk::bases_create<ozk::G2Cfg>(const uint8_t*, int, int, int, ozk::BasesHandle**);              \
+  PREFIX template int ozk::bases_msm<ozk::G2Cfg>(ozk::BasesHandle*, const uint8_t*, uint8_t*);
