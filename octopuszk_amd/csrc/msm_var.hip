@@ -194,10 +194,53 @@ int ozk_var_msm_host(const uint8_t* bases, const uint8_t* scalars, int32_t n, in
 
 int ozk_var_double_msm_host(const uint8_t* bases_g1, const uint8_t* bases_g2, const uint8_t* scalars,
                             int32_t n, int32_t task_id, uint8_t* out) {
-  // G1 then G2 on the same scalars (VariableBaseMSM.cu:1772-1773); out = G1 (192) || G2 (384)
-  int rc = ozk_var_msm_host(bases_g1, scalars, n, OZK_G1, task_id, out);
+  // G1 and G2 over the same scalars (VariableBaseMSM.cu:1772-1773); out = G1 (192) || G2 (384).
+  // The reference runs them back to back, each with its own uploads.  Here the scalars go up once, and
+  // the 192 n bytes of G2 bases are uploaded (the host thread staging pageable memory) while the G1 MSM
+  // already runs on its own stream; the G1 tail then overlaps the G2 head.
+  if (!bases_g1 || !bases_g2 || !scalars || !out) return fail(OZK_E_INVALID, "null pointer argument");
+  if (n <= 0 || n > (1 << 24)) return fail(OZK_E_INVALID, "batch_size %d out of range [1, 2^24]", n);
+  int rc = select_device(task_id);
   if (rc) return rc;
-  return ozk_var_msm_host(bases_g2, scalars, n, OZK_G2, task_id, out + 192);
+  auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const size_t b1 = (size_t)n * 96, b2 = (size_t)n * 192, sc = (size_t)n * 32;
+  const size_t w1 = var_msm_ws_bytes<G1Cfg>(n), w2 = var_msm_ws_bytes<G2Cfg>(n);
+  uint8_t* d = nullptr;
+  hipStream_t s1 = nullptr, s2 = nullptr;
+  hipEvent_t e_sc = nullptr;
+  hipError_t e = hipMalloc((void**)&d, pad(b1) + pad(b2) + pad(sc) + 1024 + pad(w1) + pad(w2) + 1024);
+  if (e != hipSuccess) return fail(OZK_E_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
+  uint8_t* d_b1 = d;
+  uint8_t* d_b2 = d_b1 + pad(b1);
+  uint8_t* d_sc = d_b2 + pad(b2);
+  uint8_t* d_out = d_sc + pad(sc);
+  uint8_t* d_w1 = d_out + 1024;
+  uint8_t* d_w2 = d_w1 + pad(w1);
+  rc = OZK_OK;
+  do {
+    if ((e = hipStreamCreateWithFlags(&s1, hipStreamNonBlocking)) != hipSuccess) break;
+    if ((e = hipStreamCreateWithFlags(&s2, hipStreamNonBlocking)) != hipSuccess) break;
+    if ((e = hipEventCreateWithFlags(&e_sc, hipEventDisableTiming)) != hipSuccess) break;
+    if ((e = hipMemcpyAsync(d_sc, scalars, sc, hipMemcpyHostToDevice, s2)) != hipSuccess) break;
+    if ((e = hipEventRecord(e_sc, s2)) != hipSuccess) break;
+    if ((e = hipMemcpyAsync(d_b1, bases_g1, b1, hipMemcpyHostToDevice, s1)) != hipSuccess) break;
+    if ((e = hipStreamWaitEvent(s1, e_sc, 0)) != hipSuccess) break;
+    if ((rc = var_msm_dev<G1Cfg>(d_b1, d_sc, n, d_out, d_w1, w1, s1))) break;
+    if ((e = hipMemcpyAsync(out, d_out, 192, hipMemcpyDeviceToHost, s1)) != hipSuccess) break;
+    if ((e = hipMemcpyAsync(d_b2, bases_g2, b2, hipMemcpyHostToDevice, s2)) != hipSuccess) break;
+    if ((rc = var_msm_dev<G2Cfg>(d_b2, d_sc, n, d_out + 256, d_w2, w2, s2))) break;
+    if ((e = hipMemcpyAsync(out + 192, d_out + 256, 384, hipMemcpyDeviceToHost, s2)) != hipSuccess) break;
+  } while (0);
+  hipError_t e1 = s1 ? hipStreamSynchronize(s1) : hipSuccess;
+  hipError_t e2 = s2 ? hipStreamSynchronize(s2) : hipSuccess;
+  if (e == hipSuccess) e = e1 != hipSuccess ? e1 : e2;
+  if (e_sc) hipEventDestroy(e_sc);
+  if (s1) hipStreamDestroy(s1);
+  if (s2) hipStreamDestroy(s2);
+  hipFree(d);
+  if (rc) return rc;
+  if (e != hipSuccess) return fail(OZK_E_NO_DEVICE, "HIP failure in var_double_msm_host: %s", hipGetErrorString(e));
+  return OZK_OK;
 }
 
 int ozk_points_sum_dev(const void* d_points, int32_t k, int32_t type, void* d_out, void* stream) {
