@@ -311,6 +311,7 @@ OZK_HD Jac<CV> jac_neg(const Jac<CV>& p) {
 
 // G1 over Fq: loop-carried bounds = fixed point of jac_madd (tools/bounds_fixpoint.py)
 struct G1Cfg {
+  static constexpr bool LDS_ACC = false;  // level-1 accumulator in registers (125 VGPRs, 4 waves per SIMD)
   using EX = Fe<FqParams, 94>;
   using EY = Fe<FqParams, 73>;
   using EZ = Fe<FqParams, 78>;

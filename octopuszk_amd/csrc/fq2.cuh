@@ -210,6 +210,7 @@ __device__ __forceinline__ Fe2<B> shfl_down_el(const Fe2<B>& v, int o) {
 // G2 over Fq2.  Loop-carried bounds: mul / sqr return < 2p, so the madd outputs are
 // X3 = sqr - (J + 2V) < 2p + 7p, Y3 < 2p + 5p, Z3 < 2p + 5p.
 struct G2Cfg {
+  static constexpr bool LDS_ACC = true;   // level-1 accumulator in LDS (msm_var.cuh RunAccLds)
   using EX = Fe2<144>;
   using EY = Fe2<112>;
   using EZ = Fe2<112>;

@@ -685,10 +685,105 @@ struct RunAcc<CV, true> {
   __device__ __forceinline__ void start(const u32* pts, const u32* idx, long long p) {
     a = xyzz_from_affine<CV>(load_signed(pts, idx, p));
   }
-  __device__ __forceinline__ void add(const u32* pts, const u32* idx, long long p) {
+  __device__ __forceinline__ void accumulate(const u32* pts, const u32* idx, long long p) {
     a = xyzz_madd(a, load_signed(pts, idx, p));
   }
   __device__ __forceinline__ void store(u32* dst) const { IO::store_rec_xyzz(a, dst); }
+  // neutral element in the XYZZ record format (chunk cut on both sides)
+  __device__ __forceinline__ void store_infinity(u32* dst) const {
+    Xyzz<CV> z = a;
+    z.ZZ = typename CV::XZZ(el_zero(z.ZZ));
+    z.ZZZ = typename CV::XZZZ(el_zero(z.ZZ));
+    IO::store_rec_xyzz(z, dst);
+  }
+};
+
+// The same accumulator kept in LDS (one column of 4 x RAW_WORDS words per lane, word-major so that a
+// wave's accesses are conflict-free), for curves whose XYZZ point does not fit the register budget of
+// two waves per SIMD: with the G2 accumulator in registers the level-1 kernel takes 256 VGPRs + 159
+// AGPRs = ONE wave per SIMD.  The mixed addition is staged so that each coordinate is read right before
+// its use and written back right after (LDS traffic is ~150 words per addition against ~28 Fq
+// multiplications).
+template <class CV>
+struct RunAccLds {
+  using IO = CurveIO<CV>;
+  using EA = typename CV::EA;
+  static constexpr int RW = IO::RW;
+  static constexpr int LDS_WORDS = 4 * RW;  // per lane
+  u32* col;                                 // this lane's column: word k at col[k * blockDim.x]
+  template <class E>
+  __device__ __forceinline__ E ld(int c) const {
+    u32 w[RW];
+#pragma unroll
+    for (int k = 0; k < RW; k++) w[k] = col[(size_t)(c * RW + k) * 256];
+    return ElemTraits<E>::load_raw(w);
+  }
+  template <class E>
+  __device__ __forceinline__ void st(int c, const E& e) const {
+    u32 w[RW];
+    ElemTraits<E>::store_raw(e, w);
+#pragma unroll
+    for (int k = 0; k < RW; k++) col[(size_t)(c * RW + k) * 256] = w[k];
+  }
+  __device__ __forceinline__ void init(u32* lds) { col = lds + threadIdx.x; }
+  __device__ __forceinline__ void put(const Xyzz<CV>& a) const {
+    st(0, a.X);
+    st(1, a.Y);
+    st(2, a.ZZ);
+    st(3, a.ZZZ);
+  }
+  __device__ __forceinline__ void start(const u32* pts, const u32* idx, long long p) {
+    put(xyzz_from_affine<CV>(RunAcc<CV, true>::load_signed(pts, idx, p)));
+  }
+  // madd-2008-s, staged over the LDS-resident accumulator
+  __device__ __forceinline__ void accumulate(const u32* pts, const u32* idx, long long p) {
+    const Aff<EA> q = RunAcc<CV, true>::load_signed(pts, idx, p);
+    if (is_inf(q)) return;
+    const auto ZZ = ld<typename CV::XZZ>(2);
+    if (is_zero(ZZ)) {  // accumulator at infinity
+      put(xyzz_from_affine<CV>(q));
+      return;
+    }
+    const auto U2 = mul(q.x, ZZ);
+    const auto P = sub(U2, ld<typename CV::XX>(0));
+    const auto ZZZ = ld<typename CV::XZZZ>(3);
+    const auto R = sub(mul(q.y, ZZZ), ld<typename CV::XY>(1));
+    if (is_zero(P)) {
+      if (is_zero(R)) {
+        put(xyzz_dbl_affine<CV>(q));  // P == Q
+      } else {                        // P == -Q
+        st(2, typename CV::XZZ(el_zero(q.x)));
+        st(3, typename CV::XZZZ(el_zero(q.x)));
+      }
+      return;
+    }
+    const auto PP = sqr(P);
+    const auto PPP = mul(P, PP);
+    st(2, typename CV::XZZ(mul(ZZ, PP)));
+    st(3, typename CV::XZZZ(mul(ZZZ, PPP)));
+    asm volatile("" ::: "memory");  // keep the reloads below where they are written
+    const auto Q = mul(ld<typename CV::XX>(0), PP);
+    const auto X3 = sub(sqr(R), add(PPP, dbl(Q)));
+    st(0, typename CV::XX(X3));
+    asm volatile("" ::: "memory");
+    const auto Y3 = sub(mul(R, sub(Q, X3)), mul(ld<typename CV::XY>(1), PPP));
+    st(1, typename CV::XY(Y3));
+  }
+  __device__ __forceinline__ Xyzz<CV> get() const {
+    Xyzz<CV> a;
+    a.X = ld<typename CV::XX>(0);
+    a.Y = ld<typename CV::XY>(1);
+    a.ZZ = ld<typename CV::XZZ>(2);
+    a.ZZZ = ld<typename CV::XZZZ>(3);
+    return a;
+  }
+  __device__ __forceinline__ void store(u32* dst) const { IO::store_rec_xyzz(get(), dst); }
+  __device__ __forceinline__ void store_infinity(u32* dst) const {
+    Xyzz<CV> z = get();
+    z.ZZ = typename CV::XZZ(el_zero(z.ZZ));
+    z.ZZZ = typename CV::XZZZ(el_zero(z.ZZ));
+    IO::store_rec_xyzz(z, dst);
+  }
 };
 template <class CV>
 struct RunAcc<CV, false> {
@@ -697,7 +792,7 @@ struct RunAcc<CV, false> {
   __device__ __forceinline__ void start(const u32* pts, const u32*, long long p) {
     a = IO::load_rec(pts + (size_t)p * IO::REC_WORDS);
   }
-  __device__ __forceinline__ void add(const u32* pts, const u32*, long long p) {
+  __device__ __forceinline__ void accumulate(const u32* pts, const u32*, long long p) {
     a = jac_add(a, IO::load_rec(pts + (size_t)p * IO::REC_WORDS));
   }
   __device__ __forceinline__ void store(u32* dst) const { IO::store_rec_jac(a, dst); }
@@ -731,7 +826,12 @@ segreduce_lane(const int t, const u32* __restrict__ bid_in, const u32* __restric
     const bool cf = (e < n_in) && (bid_in[e] == last_bid) && (last_bid != BID_NONE);
     u32 cur = BID_NONE;
     bool cur_cb = false;
-    RunAcc<CV, FIRST> acc;
+    using Acc = std::conditional_t<(FIRST && CV::LDS_ACC), RunAccLds<CV>, RunAcc<CV, FIRST>>;
+    Acc acc;
+    if constexpr (FIRST && CV::LDS_ACC) {
+      extern __shared__ u32 ozk_acc_lds[];
+      acc.init(ozk_acc_lds);
+    }
     for (long long p = s; p < e; p++) {
       const u32 b = bid_in[p];
       if (b != cur) {
@@ -747,7 +847,7 @@ segreduce_lane(const int t, const u32* __restrict__ bid_in, const u32* __restric
         cur_cb = (p == s) && cb;
         if (b != BID_NONE) acc.start(pts_in, idx_in, p);
       } else if (b != BID_NONE) {
-        acc.add(pts_in, idx_in, p);
+        acc.accumulate(pts_in, idx_in, p);
       }
     }
     if (cur != BID_NONE) {  // last run of the chunk
@@ -757,10 +857,7 @@ segreduce_lane(const int t, const u32* __restrict__ bid_in, const u32* __restric
         if (cf) {  // cut on both sides: neutral element keeps the pieces adjacent
           tail_bid = cur;
           if constexpr (FIRST) {
-            Xyzz<CV> z = acc.a;
-            z.ZZ = typename CV::XZZ(el_zero(z.ZZ));
-            z.ZZZ = typename CV::XZZZ(el_zero(z.ZZ));
-            IO::store_rec_xyzz(z, pts_out + (size_t)(2 * (size_t)t + 1) * IO::REC_WORDS);
+            acc.store_infinity(pts_out + (size_t)(2 * (size_t)t + 1) * IO::REC_WORDS);
           } else {
             IO::store_rec_jac(jac_infinity<CV>(), pts_out + (size_t)(2 * (size_t)t + 1) * IO::REC_WORDS);
           }
@@ -778,7 +875,7 @@ segreduce_lane(const int t, const u32* __restrict__ bid_in, const u32* __restric
 }
 
 template <class CV, bool FIRST>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, (FIRST && CV::LDS_ACC) ? 2 : 1)
 k_segreduce(const u32* __restrict__ bid_in, const u32* __restrict__ idx_in, const u32* __restrict__ pts_in,
             const u32* __restrict__ d_count, int n_in_static, int L,
             u32* __restrict__ buckets, u32* __restrict__ bid_out, u32* __restrict__ pts_out,

@@ -303,7 +303,11 @@ int var_msm_accum(int n, void* sorted, size_t sorted_bytes, void* accum_ws, size
   size_t lanes = (L.cap + p.L1 - 1) / p.L1;
   const bool prof = g_prof.on && g_prof.created && g_prof.count < ProfState::MAXP;
   if (prof) hipEventRecord(g_prof.e0[g_prof.count], st);
-  hipLaunchKernelGGL((k_segreduce<CV, true>), dim3((unsigned)((lanes + TB - 1) / TB)), dim3(TB), 0, st,
+  const size_t acc_lds = CV::LDS_ACC ? (size_t)RunAccLds<CV>::LDS_WORDS * TB * sizeof(u32) : 0;  // 72 KiB for G2
+  if (acc_lds > 65536)
+    OZK_HIP(hipFuncSetAttribute((const void*)(k_segreduce<CV, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)acc_lds));
+  hipLaunchKernelGGL((k_segreduce<CV, true>), dim3((unsigned)((lanes + TB - 1) / TB)), dim3(TB), acc_lds, st,
                      L.sbid, L.sidx, L.aff, L.total, 0, p.L1, L.buckets, L.slot_bid[0], L.slot_pts[0],
                      (int)lanes);
   if (prof) hipEventRecord(g_prof.e1[g_prof.count++], st);
