@@ -566,15 +566,59 @@ static __global__ void __launch_bounds__(SORT_BLOCK) k_sort2(const u32* __restri
       sbid[b0 + j] = bucket0 + (v & lo_mask);
     }
   } else {
-    for (u32 e = b0 + threadIdx.x; e - threadIdx.x < b1; e += SORT_BLOCK) {
-      const bool live = e < b1;
-      const u32 v = live ? coarse[e] : 0u;
-      const u32 lo = v & lo_mask;
-      const u32 pos = lds_rank(cur, lo, live);
-      if (live) {
+    // Larger bins (n >= 2^21: 16384 and more entries per bin) go tile by tile through the same register
+    // tile + LDS staging: per tile a local count, a local scan, a local rank into the staging array,
+    // then every bucket's piece of the tile is appended to its run in the output — consecutive lanes
+    // write consecutive words.  (The plain two-sweep form with scattered 4-byte writes took 0.59 ms at
+    // 2^21 and 2.9 ms at 2^23.)
+    __shared__ u32 tcnt[256], lcur[256], gdelta[256];
+    for (u32 t0 = b0; t0 < b1; t0 += S2_TILE) {  // uniform trip count
+      const u32 t1 = (t0 + S2_TILE < b1) ? t0 + S2_TILE : b1;
+      tcnt[threadIdx.x] = 0;
+      block_sync();
+#pragma unroll
+      for (int k = 0; k < S2_PER; k++) {
+        const u32 e = t0 + k * SORT_BLOCK + threadIdx.x;
+        vreg[k] = (e < t1) ? coarse[e] : 0xffffffffu;
+      }
+#pragma unroll
+      for (int k = 0; k < S2_PER; k++) {
+        const u32 e = t0 + k * SORT_BLOCK + threadIdx.x;
+        lds_rank(tcnt, vreg[k] & lo_mask, e < t1);
+      }
+      block_sync();
+      const u32 tc = tcnt[t];
+      u32 ti = tc;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const u32 x = __shfl_up(ti, o);
+        if (lane >= o) ti += x;
+      }
+      if (lane == 63) wsum[t >> 6] = ti;
+      block_sync();
+      u32 two = 0;
+      for (int k = 0; k < (t >> 6); k++) two += wsum[k];
+      const u32 lstart = two + ti - tc;    // start of this bucket's piece inside the staged tile
+      lcur[t] = lstart;
+      gdelta[t] = cur[t] - lstart;         // output position = staged position + gdelta
+      cur[t] += tc;
+      block_sync();
+#pragma unroll
+      for (int k = 0; k < S2_PER; k++) {
+        const u32 e = t0 + k * SORT_BLOCK + threadIdx.x;
+        const bool live = e < t1;
+        const u32 r = lds_rank(lcur, vreg[k] & lo_mask, live);
+        if (live) stage[r] = vreg[k];
+      }
+      block_sync();
+      for (u32 j = threadIdx.x; j < t1 - t0; j += SORT_BLOCK) {
+        const u32 v = stage[j];
+        const u32 lo = v & lo_mask;
+        const u32 pos = j + gdelta[lo];
         sidx[pos] = (v >> 8) | ((v & sign_bit) << 24);
         sbid[pos] = bucket0 + lo;
       }
+      block_sync();
     }
   }
 }
