@@ -1,0 +1,20 @@
+"""One host thread, S streams, complete 2^20 G1 MSMs issued round-robin (ozk_var_msm_dev, no ordering between
+streams).  streams_throughput.py <streams> [<reps>]"""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from octopuszk_amd import device as dev
+S = int(sys.argv[1]); reps = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+n = 1 << 20
+bases = dev.gen_g1_bases(n, seed=2)
+sc = np.random.default_rng(10).integers(0, 256, size=(n, 32), dtype=np.uint8); sc[:, 31] &= 0x1F
+d_sc = torch.from_numpy(sc.reshape(-1)).cuda()
+wss = [dev.VarMsmWorkspace(n, 1) for _ in range(S)]
+streams = [torch.cuda.Stream() for _ in range(S)]
+def run(k):
+    for i in range(k):
+        with torch.cuda.stream(streams[i % S]):
+            wss[i % S].run(bases, d_sc)
+run(2 * S); torch.cuda.synchronize()
+t0 = time.perf_counter(); run(reps); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+print("streams %d: %.1f Mscalar-mul/s (%.3f ms per MSM)" % (S, reps * n / dt / 1e6, dt / reps * 1e3), flush=True)
