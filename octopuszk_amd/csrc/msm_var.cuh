@@ -9,19 +9,27 @@
 // are unique.
 //
 // Pipeline (one launch each, all windows at once, no host round trips):
-//   convert   bases wire (Jacobian, canonical) -> affine Montgomery, 64 B records
-//   digits    scalars -> c-bit digits per window
-//   sort      two-level counting sort of the (window, digit) keys: hi part across blocks with
-//             per-block LDS counts + one global scan, lo part inside one block per coarse bin;
-//             LDS atomics only
-//   segreduce level 1: every lane takes L consecutive sorted entries and accumulates runs of
-//             equal bucket id with XYZZ mixed additions (8M + 2S); complete runs go to the bucket array, runs cut by
-//             a chunk boundary become "partials" (2 slots per lane)
-//             level >= 2: same scheme over the partial slots with Jacobian adds, until
-//             one lane remains — load-balanced for ANY digit distribution (a bucket
-//             holding half the input is summed by N/2L lanes, not by one)
-//   wsum      per-window  sum_d d*B_d  by segmented running sums, 8 buckets per lane/level
-//   finalize  Horner over the windows, affine normalisation, wire-out bytes
+//   digits    scalars -> GLV split into two signed half scalars (glv.cuh), signed c-bit digit codes per
+//             window with the half scalar's sign folded in (plain unsigned 256-bit windows above 2^23)
+//   convert   bases wire (Jacobian, canonical) -> affine Montgomery 64 B records, (x, y) and (beta x, y)
+//   sort      two-level counting sort of the (window, bucket) keys: hi part across blocks with
+//             per-block LDS counts + one global scan, lo part inside one block per coarse bin
+//             (register tile + LDS staging, coalesced write-out); LDS atomics only; bins of skewed
+//             inputs are split over many blocks (k_sortbig_*)
+//   segreduce level 1: every lane takes L consecutive sorted entries and accumulates runs of equal
+//             bucket id with XYZZ mixed additions (8M + 2S), negating y where the digit is negative;
+//             complete runs go to the bucket array, runs cut by a chunk boundary become "partials"
+//             (2 slots per lane)
+//   runmerge  sums the <= 16 pieces of every cut bucket (general XYZZ additions)
+//   levels    the same segmented scheme over surviving slots with Jacobian adds, until one lane
+//             remains — load-balanced for ANY digit distribution (a bucket holding half the input
+//             is summed by N/2L lanes, not by one)
+//   wsum      per-window  sum_b (b + 1) * B_b: a fused first level (serial running sums per lane, then
+//             an in-register wave combine), wave-cooperative upper levels
+//   finalize  the last few elements per window, Horner over the windows, affine normalisation
+//             (safegcd inversion), wire-out bytes
+// Every workgroup barrier is block_sync() (curve.cuh): hipcc dropped the wait for a pending LDS atomic
+// before one s_barrier, which silently lost counts on skewed inputs.
 #pragma once
 #include "curve.cuh"
 #include "glv.cuh"

@@ -427,3 +427,37 @@ def test_prepared_pipeline_full_size():
         assert a == b
         outs.append(a)
     assert len(set(outs)) == 3
+
+
+def test_g2_mid_size_discrete_log_identity():
+    """G2 at 2^15 (the LDS-resident level-1 accumulator, signed digits, GLV on the twist): bases k_i G2
+    from the fixed-base path (itself oracle-checked in test_fixed_base_gpu.py), so that
+    sum s_i P_i = (sum s_i k_i) G2 can be checked with exact integers."""
+    import ctypes
+    import numpy as np
+    import torch
+    from octopuszk_amd import device as dev, lib
+    L = lib.load()
+    n = 1 << 15
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(88)
+    ks = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    ks[:, 8:] = 0
+    sc = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    sc[:, 31] &= 0x1F
+    base = torch.from_numpy(np.frombuffer(o.g2_to_wire(o.G2.one), dtype=np.uint8).copy()).cuda()
+    out_be = torch.empty(n * 384, dtype=torch.uint8, device="cuda")
+    wsb = int(L.ozk_fixed_batch_msm_workspace_bytes(4, 16, n, 2))
+    wsf = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    lib.check(L.ozk_fixed_batch_msm_dev(4, 16, n, p(base), p(torch.from_numpy(ks.reshape(-1)).cuda()), 2, p(out_be), p(wsf),
+                                        wsb, st))
+    torch.cuda.synchronize()
+    be = out_be.cpu().numpy().reshape(n, 6, 64)
+    assert not be[:, :, :32].any()
+    wire = np.ascontiguousarray(be[:, :, ::-1][:, :, :32]).reshape(-1).copy()
+    ws = dev.VarMsmWorkspace(n, 2)
+    out = ws.run(torch.from_numpy(wire).cuda(), torch.from_numpy(sc.reshape(-1)).cuda())
+    torch.cuda.synchronize()
+    acc = sum(int.from_bytes(sc[i].tobytes(), "little") * int.from_bytes(ks[i].tobytes(), "little") for i in range(n)) % o.R
+    assert bytes(out.cpu().numpy()) == o.g2_out_le(o.G2.to_affine(o.G2.mul(o.G2.one, acc)))
