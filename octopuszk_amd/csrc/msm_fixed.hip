@@ -16,13 +16,25 @@
 //   k_fb_level k  table[w][2^k + j] = table[w][j] + D[w*ws + k]   (windowSize launches, all
 //                 windows and all j in parallel; the reference re-doubles per window and adds
 //                 popcount(i) points per entry, FixedBaseMSM.cu:851-992)
-//   k_fb_main     per scalar: gather-add one table entry per window (Jacobian)
+//   k_fb_main     per scalar: gather-add one table entry per window (Jacobian).  Default form
+//                 (k_fb_main_glv): the scalar is split by the GLV endomorphism (glv.cuh) into two
+//                 127-bit halves that share ONE table of ceil(128 / windowSize) windows — s B =
+//                 +-(sum_w T[w][d1_w]) + phi(+-(sum_w T[w][d2_w])), phi(X, Y, Z) = (beta X, Y, Z) —
+//                 which halves the serial doubling chain (the longest single item: 254 doublings on
+//                 one lane, 1.2 ms for G1 and 5 ms for G2) and the table
 //   k_fb_norm     per lane a batch of results: one shared inversion (Montgomery's trick),
 //                 big-endian stores
 #include "fq2.cuh"
+#include "glv.cuh"
 #include "ozk_common.h"
 
 namespace ozk {
+
+template <class CV>
+__device__ __forceinline__ Fe<FqParams, 16> glv_beta_fixed() {
+  if constexpr (CurveIO<CV>::CW == 16) return fe_const<FqParams, 16>(GlvConsts::BETA_G2);
+  else return fe_const<FqParams, 16>(GlvConsts::BETA_G1);
+}
 
 template <class CV>
 __global__ void __launch_bounds__(64) k_fb_chain(const u32* __restrict__ base_wire, int total, u32* __restrict__ D) {
@@ -82,6 +94,45 @@ __global__ void __launch_bounds__(256) k_fb_main(const u32* __restrict__ scalars
     if (d != 0) acc = jac_add(acc, IO::load_jac(table + (((size_t)w << ws) + d) * IO::JAC_WORDS));
   }
   IO::store_jac(acc, jac_out + (size_t)i * IO::JAC_WORDS);
+}
+
+// GLV form of the gather-add: one table of `oc` windows covering 128 bits, two digit strings.
+template <class CV>
+__global__ void __launch_bounds__(256) k_fb_main_glv(const u32* __restrict__ scalars, const u32* __restrict__ table,
+                                                     int n, int oc, int ws, u32* __restrict__ jac_out) {
+  using IO = CurveIO<CV>;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 s[8];
+  const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
+  const uint4 a = sp[0], b = sp[1];
+  s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w;
+  s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+  u32 k1[4], k2[4];
+  bool n1, n2;
+  glv_decompose(s, k1, n1, k2, n2);
+  Jac<CV> part[2];
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const u32* k = h ? k2 : k1;
+    Jac<CV> acc = jac_infinity<CV>();
+    for (int w = 0; w < oc; w++) {
+      const int bit = w * ws;
+      u32 d = 0;
+      if (bit < 128) {
+        const int wi = bit >> 5, sh = bit & 31;
+        unsigned long long v = k[wi];
+        if (wi + 1 < 4) v |= (unsigned long long)k[wi + 1] << 32;
+        d = (u32)(v >> sh) & ((1u << ws) - 1u);
+      }
+      if (d != 0) acc = jac_add(acc, IO::load_jac(table + (((size_t)w << ws) + d) * IO::JAC_WORDS));
+    }
+    if (h ? n2 : n1) acc = jac_neg(acc);
+    part[h] = acc;
+  }
+  // phi(X, Y, Z) = (beta X, Y, Z)
+  part[1].X = typename CV::EX(reduce_to<32>(scale(part[1].X, glv_beta_fixed<CV>())));
+  IO::store_jac(jac_add(part[0], part[1]), jac_out + (size_t)i * IO::JAC_WORDS);
 }
 
 // 64-byte big-endian store of one Fq value: 8 zero words, then the value's words reversed
@@ -195,15 +246,23 @@ static int fixed_batch_dev(int outerc, int ws, int n, const void* d_base, const 
   const FbLayout L = fb_layout<CV>(outerc, ws, n, wsp, wsb);
   if (L.bytes > wsb) return fail(OZK_E_INVALID, "workspace too small: need %zu bytes, got %zu", L.bytes, wsb);
   const int TB = 256;
-  hipLaunchKernelGGL((k_fb_chain<CV>), dim3(1), dim3(64), 0, st, (const u32*)d_base, outerc * ws, L.D);
+  // GLV form when the caller's windows cover a whole Fr scalar (they always do in the reference:
+  // outerc = ceil(scalarSize / windowSize), FixedBaseMSM.java:71-99); the plain form otherwise
+  const bool glv = env_int("OZK_MSM_GLV", 1) != 0 && (long long)outerc * ws >= 254;
+  const int oc = glv ? (128 + ws - 1) / ws : outerc;
+  hipLaunchKernelGGL((k_fb_chain<CV>), dim3(1), dim3(64), 0, st, (const u32*)d_base, oc * ws, L.D);
   // entry 0 of every window is infinity: clear those records (all-zero Jacobian has Z = 0)
-  OZK_HIP(hipMemset2DAsync(L.table, ((size_t)1 << ws) * IO::JAC_WORDS * 4, 0, IO::JAC_WORDS * 4, outerc, st));
+  OZK_HIP(hipMemset2DAsync(L.table, ((size_t)1 << ws) * IO::JAC_WORDS * 4, 0, IO::JAC_WORDS * 4, oc, st));
   for (int k = 0; k < ws; k++) {
-    const int tot = outerc << k;
-    hipLaunchKernelGGL((k_fb_level<CV>), dim3((tot + TB - 1) / TB), dim3(TB), 0, st, L.table, L.D, outerc, ws, k);
+    const int tot = oc << k;
+    hipLaunchKernelGGL((k_fb_level<CV>), dim3((tot + TB - 1) / TB), dim3(TB), 0, st, L.table, L.D, oc, ws, k);
   }
-  hipLaunchKernelGGL((k_fb_main<CV>), dim3((n + TB - 1) / TB), dim3(TB), 0, st, (const u32*)d_scalars, L.table, n,
-                     outerc, ws, L.jac);
+  if (glv)
+    hipLaunchKernelGGL((k_fb_main_glv<CV>), dim3((n + TB - 1) / TB), dim3(TB), 0, st, (const u32*)d_scalars, L.table,
+                       n, oc, ws, L.jac);
+  else
+    hipLaunchKernelGGL((k_fb_main<CV>), dim3((n + TB - 1) / TB), dim3(TB), 0, st, (const u32*)d_scalars, L.table, n,
+                       outerc, ws, L.jac);
   const int lanes = (n + FB_BATCH - 1) / FB_BATCH;
   hipLaunchKernelGGL((k_fb_norm<CV>), dim3((lanes + TB - 1) / TB), dim3(TB), 0, st, L.jac, n, (u32*)d_out,
                      out_stride_words);

@@ -37,6 +37,19 @@ def test_fixed_base_g1_vs_oracle(n, window):
         assert P == o.G1.to_affine(o.fixed_base_mul(o.G1, base, 254, window, s))
 
 
+def test_fixed_base_glv_edge_scalars():
+    # the gather-add splits every scalar with the GLV endomorphism (msm_fixed.hip k_fb_main_glv)
+    from octopuszk_amd import fixed_base_msm as fb
+    lam = 4407920970296243842393367215006156084916469457145843978461
+    scalars = [0, 1, 2, o.R - 1, o.R - 2, lam, lam - 1, lam + 1, o.R - lam, (1 << 127) - 1, 1 << 127, (1 << 127) + 1,
+               1 << 128, 1 << 253, o.R // 2, 9931322734385697763, 147946756881789319010696353538189108491]
+    for C, is_g1 in ((o.G1, True), (o.G2, False)):
+        base = C.mul(C.one, 0x1234567)
+        got = fb.batch_msm(254, 17, base, scalars, is_g1=is_g1)
+        for s_, P in zip(scalars, got):
+            assert P == C.to_affine(C.mul(base, s_)), hex(s_)
+
+
 def test_fixed_base_truncates_to_outerc_windows():
     # only the first outerc windows of the scalar are used (FixedBaseMSM.java:146-164)
     from octopuszk_amd import fixed_base_msm as fb
