@@ -70,10 +70,19 @@ def main():
             raise SystemExit("--gpus %d needs the torch.distributed.run launcher (WORLD_SIZE=%d)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    # OZK_BENCH_REHEARSAL=1 (tests only): all ranks share cuda:0 and exchange over gloo, so that the
+    # N > 1 control path — sharding, all-gather of the partials, HIP point sum, max-over-ranks timing —
+    # can be exercised on a one-GPU box.  RCCL refuses two ranks on one device; the numbers mean nothing.
+    rehearsal = os.environ.get("OZK_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     L = ozk.load()
     n = 1 << args.logn
