@@ -185,6 +185,13 @@ __device__ __forceinline__ u32 opaque_zero() {
   return z;
 }
 template <class P, int B>
+__device__ __forceinline__ Fe<P, B> shfl_xor_el(const Fe<P, B>& v, int m) {
+  Fe<P, B> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = __shfl_xor(v.l[i], m);
+  return r;
+}
+template <class P, int B>
 __device__ __forceinline__ Fe<P, B> shfl_down_el(const Fe<P, B>& v, int o) {
   Fe<P, B> r;
 #pragma unroll

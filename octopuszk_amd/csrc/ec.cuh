@@ -311,6 +311,8 @@ OZK_HD Jac<CV> jac_neg(const Jac<CV>& p) {
 
 // G1 over Fq: loop-carried bounds = fixed point of jac_madd (tools/bounds_fixpoint.py)
 struct G1Cfg {
+  using Pair = G1Cfg;                     // serial chains run on one lane
+  static constexpr int PAIR_LANES = 1;
   static constexpr bool LDS_ACC = false;  // level-1 accumulator in registers (125 VGPRs, 4 waves per SIMD)
   using EX = Fe<FqParams, 94>;
   using EY = Fe<FqParams, 73>;

@@ -209,7 +209,10 @@ __device__ __forceinline__ Fe2<B> shfl_down_el(const Fe2<B>& v, int o) {
 
 // G2 over Fq2.  Loop-carried bounds: mul / sqr return < 2p, so the madd outputs are
 // X3 = sqr - (J + 2V) < 2p + 7p, Y3 < 2p + 5p, Z3 < 2p + 5p.
+struct G2CfgL;
 struct G2Cfg {
+  using Pair = G2CfgL;                    // serial chains (Horner, fixed-base doubling chain) on a lane pair
+  static constexpr int PAIR_LANES = 2;
   static constexpr bool LDS_ACC = true;   // level-1 accumulator in LDS (msm_var.cuh RunAccLds)
   using EX = Fe2<144>;
   using EY = Fe2<112>;
@@ -220,5 +223,157 @@ struct G2Cfg {
   using XZZ = Fe2<32>;
   using XZZZ = Fe2<32>;
 };
+
+#if defined(__HIPCC__)
+// ---- Fq2 on a LANE PAIR, for the serial chains -------------------------------------------------
+// A lone lane runs a G2 doubling (5 Fq2 squarings + 2 Fq2 multiplications = 16 Fq multiplications) in
+// ~20 us, and both the Horner kernel (120 of them) and the fixed-base doubling chain are exactly that.
+// Fe2L is the same element held IDENTICALLY by two adjacent lanes (an even / odd pair): the two Fq
+// products of a squaring, and two of the three of a Karatsuba multiplication, run side by side, one per
+// lane, and are exchanged with one __shfl_xor per limb; everything else is computed redundantly, so the
+// pair never diverges.  The generic group law (ec.cuh) runs unchanged over G2CfgL.
+template <int B>
+struct Fe2L {
+  Fe<FqParams, B> c0, c1;
+  __device__ __forceinline__ Fe2L() {}
+  template <int B2, class = std::enable_if_t<(B2 <= B)>>
+  __device__ __forceinline__ Fe2L(const Fe2L<B2>& o) : c0(o.c0), c1(o.c1) {}
+};
+template <int B>
+__device__ __forceinline__ Fe2L<B> to_pair(const Fe2<B>& a) {
+  Fe2L<B> r;
+  r.c0 = a.c0;
+  r.c1 = a.c1;
+  return r;
+}
+template <int B>
+__device__ __forceinline__ Fe2<B> from_pair(const Fe2L<B>& a) {
+  Fe2<B> r;
+  r.c0 = a.c0;
+  r.c1 = a.c1;
+  return r;
+}
+template <int B>
+__device__ __forceinline__ Fe2L<1> el_zero(const Fe2L<B>&) {
+  Fe2L<1> r;
+  r.c0 = fe_zero<FqParams>();
+  r.c1 = fe_zero<FqParams>();
+  return r;
+}
+template <int B>
+__device__ __forceinline__ Fe2L<16> el_one(const Fe2L<B>&) {
+  Fe2L<16> r;
+  r.c0 = fe_one<FqParams>();
+  r.c1 = Fe<FqParams, 16>(fe_zero<FqParams>());
+  return r;
+}
+template <int B1, int B2>
+__device__ __forceinline__ auto add(const Fe2L<B1>& a, const Fe2L<B2>& b) {
+  Fe2L<B1 + B2> r;
+  r.c0 = add(a.c0, b.c0);
+  r.c1 = add(a.c1, b.c1);
+  return r;
+}
+template <int B1>
+__device__ __forceinline__ auto dbl(const Fe2L<B1>& a) {
+  Fe2L<2 * B1> r;
+  r.c0 = dbl(a.c0);
+  r.c1 = dbl(a.c1);
+  return r;
+}
+template <int B1, int B2>
+__device__ __forceinline__ auto sub(const Fe2L<B1>& a, const Fe2L<B2>& b) {
+  Fe2L<B1 + 16 * (B2 / 16 + 1)> r;
+  r.c0 = sub(a.c0, b.c0);
+  r.c1 = sub(a.c1, b.c1);
+  return r;
+}
+template <int B2>
+__device__ __forceinline__ auto neg(const Fe2L<B2>& b) {
+  Fe2L<16 * (B2 / 16 + 1)> r;
+  r.c0 = neg(b.c0);
+  r.c1 = neg(b.c1);
+  return r;
+}
+template <int TB, int B>
+__device__ __forceinline__ auto reduce_to(const Fe2L<B>& a) {
+  if constexpr (B <= TB) {
+    return a;
+  } else {
+    Fe2L<TB> r;
+    r.c0 = Fe<FqParams, TB>(reduce_to<TB>(a.c0));
+    r.c1 = Fe<FqParams, TB>(reduce_to<TB>(a.c1));
+    return r;
+  }
+}
+template <int B>
+__device__ __forceinline__ bool is_zero(const Fe2L<B>& a) {
+  return is_zero(a.c0) && is_zero(a.c1);
+}
+// lane 0 of the pair: (a0 + a1)(a0 - a1); lane 1: a0 a1
+template <int B1>
+__device__ __forceinline__ Fe2L<32> sqr(const Fe2L<B1>& a_in) {
+  if constexpr (B1 > 32) {
+    return sqr(reduce_to<32>(a_in));
+  } else {
+    const bool odd = (threadIdx.x & 1) != 0;
+    const auto s = add(a_in.c0, a_in.c1);
+    const auto d = sub(a_in.c0, a_in.c1);
+    using TS = std::decay_t<decltype(s)>;
+    using TD = std::decay_t<decltype(d)>;
+    const TS x = select_el(odd, TS(a_in.c0), s);
+    const TD y = select_el(odd, TD(a_in.c1), d);
+    const auto p = mul(x, y);
+    const auto q = shfl_xor_el(p, 1);
+    const auto t0 = select_el(odd, q, p);  // (a0 + a1)(a0 - a1)
+    const auto t1 = select_el(odd, p, q);  // a0 a1
+    Fe2L<32> r;
+    r.c0 = Fe<FqParams, 32>(reduce_to<32>(t0));
+    r.c1 = Fe<FqParams, 32>(reduce_to<32>(dbl(t1)));
+    return r;
+  }
+}
+// lane 0: a0 b0, lane 1: a1 b1, then both: (a0 + a1)(b0 + b1)
+template <int B1, int B2>
+__device__ __forceinline__ Fe2L<32> mul(const Fe2L<B1>& a_in, const Fe2L<B2>& b_in) {
+  if constexpr (!kara_ok(B1, B2)) {
+    return mul(reduce_to<(B1 > 32 ? 32 : B1)>(a_in), reduce_to<(B2 > 32 ? 32 : B2)>(b_in));
+  } else {
+    const bool odd = (threadIdx.x & 1) != 0;
+    const auto p = mul(select_el(odd, a_in.c1, a_in.c0), select_el(odd, b_in.c1, b_in.c0));
+    const auto q = shfl_xor_el(p, 1);
+    const auto v0 = select_el(odd, q, p);
+    const auto v1 = select_el(odd, p, q);
+    const auto s = mul(add(a_in.c0, a_in.c1), add(b_in.c0, b_in.c1));
+    Fe2L<32> r;
+    r.c0 = Fe<FqParams, 32>(reduce_to<32>(sub(v0, v1)));
+    r.c1 = Fe<FqParams, 32>(reduce_to<32>(sub(s, add(v0, v1))));
+    return r;
+  }
+}
+struct G2CfgL {
+  using EX = Fe2L<144>;
+  using EY = Fe2L<112>;
+  using EZ = Fe2L<112>;
+};
+__device__ __forceinline__ Jac<G2CfgL> to_pair(const Jac<G2Cfg>& p) {
+  Jac<G2CfgL> r;
+  r.X = to_pair(p.X);
+  r.Y = to_pair(p.Y);
+  r.Z = to_pair(p.Z);
+  return r;
+}
+__device__ __forceinline__ Jac<G2Cfg> from_pair(const Jac<G2CfgL>& p) {
+  Jac<G2Cfg> r;
+  r.X = from_pair(p.X);
+  r.Y = from_pair(p.Y);
+  r.Z = from_pair(p.Z);
+  return r;
+}
+template <class CV>
+__device__ __forceinline__ const Jac<CV>& to_pair(const Jac<CV>& p) { return p; }   // one-lane curves: identity
+template <class CV>
+__device__ __forceinline__ const Jac<CV>& from_pair(const Jac<CV>& p) { return p; }
+#endif
 
 }  // namespace ozk

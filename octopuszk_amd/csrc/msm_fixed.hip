@@ -39,11 +39,12 @@ __device__ __forceinline__ Fe<FqParams, 16> glv_beta_fixed() {
 template <class CV>
 __global__ void __launch_bounds__(64) k_fb_chain(const u32* __restrict__ base_wire, int total, u32* __restrict__ D) {
   using IO = CurveIO<CV>;
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  using CP = typename CV::Pair;  // G2: the chain runs on a lane pair (Fe2L, fq2.cuh)
+  if (blockIdx.x != 0 || threadIdx.x >= CV::PAIR_LANES) return;
   base_wire += opaque_zero();
-  Jac<CV> p = IO::jac_from_wire(base_wire);
+  Jac<CP> p = to_pair(IO::jac_from_wire(base_wire));
   for (int j = 0; j < total; j++) {
-    IO::store_jac(p, D + (size_t)j * IO::JAC_WORDS);
+    if (threadIdx.x == 0) IO::store_jac(from_pair(p), D + (size_t)j * IO::JAC_WORDS);
     p = jac_dbl(p);
   }
 }

@@ -1195,17 +1195,22 @@ __global__ void __launch_bounds__(EXCLUSIVE ? 256 : 64) k_finalize(const u32* __
   __builtin_amdgcn_s_setprio(3);
   // The last window-sum level left m (<= a few) elements (A_j, R_j) per window:
   //     S_w = sum_j A_j + 2^g * sum_j j * R_j     (+ sum_j R_j with signed digits: bucket b weighs b + 1)
-  // — lane w finishes window w (all windows in parallel), then lane 0 runs Horner over the S_w.
+  // — window w is finished by lane w (G2: by the lane pair 2w, 2w + 1, see Fe2L in fq2.cuh), all windows
+  // in parallel; then lane 0 (the pair 0, 1) runs Horner over the S_w.
+  using CP = typename CV::Pair;
+  constexpr int LP = CV::PAIR_LANES;
+  constexpr int WB = 64 / LP;  // windows per batch
   const int l = threadIdx.x;
-  Jac<CV> r = jac_infinity<CV>();
-  for (int w0 = ((W - 1) / 64) * 64; w0 >= 0; w0 -= 64) {  // (W <= 64 unless the window size is forced tiny)
-    const int w = w0 + l;
+  const int wl = l / LP;
+  Jac<CP> r = jac_infinity<CP>();
+  for (int w0 = ((W - 1) / WB) * WB; w0 >= 0; w0 -= WB) {  // (one batch unless the window size is forced tiny)
+    const int w = w0 + wl;
     if (w < W) {
-      Jac<CV> run = jac_infinity<CV>(), acc = jac_infinity<CV>(), asum = jac_infinity<CV>();
+      Jac<CP> run = jac_infinity<CP>(), acc = jac_infinity<CP>(), asum = jac_infinity<CP>();
       for (int j = m - 1; j >= 0; j--) {
-        asum = jac_add(asum, IO::load_jac(A_w + ((size_t)w * m + j) * IO::JAC_WORDS));
+        asum = jac_add(asum, to_pair(IO::load_jac(A_w + ((size_t)w * m + j) * IO::JAC_WORDS)));
         if (j >= 1) {
-          run = jac_add(run, IO::load_jac(R_w + ((size_t)w * m + j) * IO::JAC_WORDS));
+          run = jac_add(run, to_pair(IO::load_jac(R_w + ((size_t)w * m + j) * IO::JAC_WORDS)));
           acc = jac_add(acc, run);
         }
       }
@@ -1214,24 +1219,24 @@ __global__ void __launch_bounds__(EXCLUSIVE ? 256 : 64) k_finalize(const u32* __
         asum = jac_add(asum, acc);
       }
       if (sd) {
-        run = jac_add(run, IO::load_jac(R_w + (size_t)w * m * IO::JAC_WORDS));  // + R_0: all buckets
+        run = jac_add(run, to_pair(IO::load_jac(R_w + (size_t)w * m * IO::JAC_WORDS)));  // + R_0: all buckets
         asum = jac_add(asum, run);
       }
-      IO::store_jac(asum, sw + (size_t)l * IO::JAC_WORDS);
+      if (l % LP == 0) IO::store_jac(from_pair(asum), sw + (size_t)wl * IO::JAC_WORDS);
     }
     __builtin_amdgcn_wave_barrier();
-    if (l == 0) {
+    if (l < LP) {
       const u32* sp = sw + opaque_zero();
-      const int top = (W - w0 < 64) ? (W - w0) : 64;
+      const int top = (W - w0 < WB) ? (W - w0) : WB;
       for (int i = top - 1; i >= 0; i--) {
         for (int k = 0; k < c; k++) r = jac_dbl(r);  // no-op while r is infinity
-        r = jac_add(r, IO::load_jac(sp + (size_t)i * IO::JAC_WORDS));
+        r = jac_add(r, to_pair(IO::load_jac(sp + (size_t)i * IO::JAC_WORDS)));
       }
     }
     __builtin_amdgcn_wave_barrier();
   }
   if (l == 0) {
-    write_normalised<CV>(r, out);
+    write_normalised<CV>(from_pair(r), out);
     done = 1;
   }
 }
