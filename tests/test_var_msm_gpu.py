@@ -461,3 +461,47 @@ def test_g2_mid_size_discrete_log_identity():
     torch.cuda.synchronize()
     acc = sum(int.from_bytes(sc[i].tobytes(), "little") * int.from_bytes(ks[i].tobytes(), "little") for i in range(n)) % o.R
     assert bytes(out.cpu().numpy()) == o.g2_out_le(o.G2.to_affine(o.G2.mul(o.G2.one, acc)))
+
+
+def test_host_entry_points_are_thread_safe():
+    """The reference's natives are called from concurrent Spark task threads: four host
+    threads issue G1 / G2 / prepared MSMs at the same time; every result must equal the sequential one."""
+    import threading
+    from octopuszk_amd import variable_base_msm as vb
+    rng = random.Random(91)
+    jobs = []
+    for k in range(8):
+        type_ = 1 if k % 3 else 2
+        G = o.G1 if type_ == 1 else o.G2
+        n = 3000 + 17 * k if type_ == 1 else 300 + k
+        pts = _rand_points(G, 24, rng)
+        bases = [pts[i % 24] for i in range(n)]
+        wire = vb.marshal_g1(bases) if type_ == 1 else vb.marshal_g2(bases)
+        sw = vb.marshal_scalars([rng.randrange(o.R) for _ in range(n)])
+        jobs.append((wire, sw, n, type_))
+    want = [vb.variable_base_serial_msm_native_helper(w, s, n, t, 0) for (w, s, n, t) in jobs]
+    got = [[None] * len(jobs) for _ in range(4)]
+    errs = []
+
+    def worker(tid):
+        try:
+            for rep in range(2):
+                for j in range(tid, len(jobs) + tid):
+                    w, s, n, t = jobs[j % len(jobs)]
+                    if (j + rep) % 2:
+                        got[tid][j % len(jobs)] = vb.variable_base_serial_msm_native_helper(w, s, n, t, tid)
+                    else:
+                        pb = vb.PreparedBases(w, n, t, tid)
+                        got[tid][j % len(jobs)] = pb.msm(s)
+                        pb.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    ths = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert errs == []
+    for tid in range(4):
+        assert got[tid] == want
