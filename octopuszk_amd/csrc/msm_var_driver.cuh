@@ -281,7 +281,7 @@ int var_msm_sort(const void* d_bases, const void* d_scalars, int n, void* sorted
   // Ordering hint for pipelined MSMs (see ozk_var_msm_tail_ordered_dev): everything up to here may
   // overlap the previous MSM's window-sum levels; the bucket accumulation that follows fills every
   // SIMD's register file, so the previous MSM's single-wave Horner kernel has to be resident first.
-  if (order_ev) OZK_HIP(hipStreamWaitEvent(st, order_ev, 0));
+  if (order_ev && env_int("OZK_MSM_ORDER", 1)) OZK_HIP(hipStreamWaitEvent(st, order_ev, 0));
   // bins above the threshold (skewed digits), split over a fixed grid; no-ops otherwise
   hipLaunchKernelGGL(k_sortbig_list, dim3(1), dim3(256), 0, st, L.P1, L.total, L.nblk, nbins, big_thresh, L.bigbins);
   hipLaunchKernelGGL(k_sortbig_count, dim3(1024), dim3(SORT_BLOCK), 0, st, L.coarse, L.bigbins,
@@ -313,7 +313,14 @@ int var_msm_accum(int n, void* sorted, size_t sorted_bytes, void* accum_ws, size
   size_t lanes = (L.cap + p.L1 - 1) / p.L1;
   const bool prof = g_prof.on && g_prof.created && g_prof.count < ProfState::MAXP;
   if (prof) hipEventRecord(g_prof.e0[g_prof.count], st);
-  const size_t acc_lds = CV::LDS_ACC ? (size_t)RunAccLds<CV>::LDS_WORDS * TB * sizeof(u32) : 0;  // 72 KiB for G2
+  size_t acc_lds = CV::LDS_ACC ? (size_t)RunAccLds<CV>::LDS_WORDS * TB * sizeof(u32) : 0;  // 72 KiB for G2
+  // G1: the kernel needs no LDS, but 4 blocks of 4 x 128 VGPRs fill a CU's register files completely, and a
+  // kernel of another stream (a concurrent MSM's tail) dispatched later finds no wave slot until a block
+  // retires (~0.7 ms).  Asking for 48 KiB of dynamic LDS caps it at 3 blocks per CU — one wave slot per
+  // SIMD stays free.  Measured: the kernel itself is as fast with 3 waves per SIMD as with 4 (1.404 vs
+  // 1.409 ms); two free-running MSM streams 416 -> 459 Mscalar-mul/s; the pipelined bench without the
+  // launch-order hint 417 -> 476 (with it: unchanged, 480).
+  if (!CV::LDS_ACC) acc_lds = (size_t)env_int("OZK_L1_LDS", 49152);
   if (acc_lds > 65536)
     OZK_HIP(hipFuncSetAttribute((const void*)(k_segreduce<CV, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)acc_lds));
