@@ -52,10 +52,18 @@ def main():
     ap.add_argument("--prepared", action="store_true",
                     help="bases prepared once outside the timed region (ozk_var_msm_prepare_dev): NOT the "
                          "BASELINE.json workload, whose every MSM starts from the JNI wire bytes")
-    ap.add_argument("--in-flight", type=int, default=2,
-                    help="MSMs in flight: the latency-bound tail of step k runs on a side stream while the "
-                         "head of step k+1 runs (1 = strictly serial steps)")
+    ap.add_argument("--in-flight", type=int, default=None,
+                    help="MSMs in flight (default: 3 for --schedule streams, 2 for pipeline; 1 = strictly serial steps)")
+    ap.add_argument("--schedule", choices=["streams", "pipeline"], default="pipeline",
+                    help="pipeline (default): one head stream + one tail stream with the launch-order hint "
+                         "(device.VarMsmPipeline) — the level-1 kernel runs alone, so its HIP-event duration is the "
+                         "kernel's own; streams: complete MSMs issued round-robin on independent streams, the way "
+                         "concurrent prover threads drive the JNI — ~6 %% more throughput at 3 in flight (513-527 "
+                         "Mscalar-mul/s), but the overlapping level-1 kernels stretch each other's duration, which "
+                         "would distort `roofline`")
     args = ap.parse_args()
+    if args.in_flight is None:
+        args.in_flight = 3 if args.schedule == "streams" else 2
 
     import torch
     import torch.distributed as dist
@@ -114,8 +122,26 @@ def main():
 
     finish.last_event = None
 
+    S = max(1, args.in_flight)
+    wss = [dev.VarMsmWorkspace(n, 1) for _ in range(S)] if args.schedule == "streams" else []
+    sts = [torch.cuda.Stream() for _ in range(S)] if args.schedule == "streams" else []
+    issued = [0]
+
+    def run_steps_streams(k):
+        """k complete MSMs, round-robin over S independent streams (each MSM: head and tail on its stream)."""
+        res = None
+        for _ in range(k):
+            i = issued[0] % S
+            issued[0] += 1
+            with torch.cuda.stream(sts[i]):
+                res = ozk_dist.distributed_var_msm(lambda: wss[i].run(msm_bases, scalars, prepared=args.prepared),
+                                                   dev.points_sum, 1)
+        return res
+
     def run_steps(k):
         """k complete MSMs; step i's tail overlaps step i+1's head (args.in_flight > 1)."""
+        if args.schedule == "streams":
+            return run_steps_streams(k)
         res, prev = None, None
         for _ in range(k):
             t = pipe.submit(msm_bases, scalars, prepared=args.prepared)
@@ -148,7 +174,7 @@ def main():
     for _ in range(5):
         torch.cuda.synchronize()
         l0 = time.perf_counter()
-        finish(pipe.submit(msm_bases, scalars, prepared=args.prepared))
+        run_steps(1)
         torch.cuda.synchronize()
         lat.append(time.perf_counter() - l0)
     single_ms = sorted(lat)[len(lat) // 2] * 1e3
@@ -206,7 +232,8 @@ def main():
                                        "the serial CPU path (BASELINE.json configs[1])" % args.logn,
                            "n_per_gpu": n, "window_bits": wb.value, "windows": wn.value, "glv": bool(glv),
                            "prepared_bases": bool(args.prepared),
-                           "msms_in_flight": max(1, args.in_flight), "single_msm_latency_ms": round(single_ms, 3),
+                           "msms_in_flight": max(1, args.in_flight), "schedule": args.schedule,
+                           "single_msm_latency_ms": round(single_ms, 3),
                            "parallelism": "index-range shard x%d, RCCL all-gather of 192-B partials + HIP point sum" % world},
                 "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)

@@ -31,13 +31,15 @@ class VarMsmWorkspace:
         self.ws = torch.empty(self.bytes, dtype=torch.uint8, device=device)
         self.out = torch.zeros(192 if type_ == 1 else 384, dtype=torch.uint8, device=device)
 
-    def run(self, d_bases, d_scalars):
-        """d_bases: uint8 [n*96|192], d_scalars: uint8 [n*32] — wire format, in HBM.
+    def run(self, d_bases, d_scalars, prepared=False):
+        """d_bases: uint8 [n*96|192] wire format (or the records of ozk_var_msm_prepare_dev with
+        prepared=True), d_scalars: uint8 [n*32], in HBM.
         Asynchronous on the current stream; returns the output tensor (192|384 B)."""
         L = _lib.load()
         self._inputs = (d_bases, d_scalars)
-        _lib.check(L.ozk_var_msm_dev(_ptr(d_bases), _ptr(d_scalars), self.n, self.type, _ptr(self.out),
-                                     _ptr(self.ws), self.bytes, _stream()))
+        fn = L.ozk_var_msm_prepared_dev if prepared else L.ozk_var_msm_dev
+        _lib.check(fn(_ptr(d_bases), _ptr(d_scalars), self.n, self.type, _ptr(self.out), _ptr(self.ws), self.bytes,
+                      _stream()))
         return self.out
 
 
