@@ -11,7 +11,9 @@ scalars) to the 192-byte affine-normalised result.  With N GPUs every rank owns 
 partials over RCCL and each adds them up with the HIP point-sum kernel — the
 Spark `mapPartitions -> reduce(add)` of VariableBaseMSM.java:777-783.
 
-Prints ONE JSON line (rank 0).  `value` = N * 2^20 * K / wall-time / 1e6 Mscalar-mul/s,
+Steps overlap: by default two MSMs are in flight on a head stream and a tail stream
+(device.VarMsmPipeline); `--schedule streams` issues complete MSMs round-robin on independent
+streams instead (see --help).  Prints ONE JSON line (rank 0).  `value` = N * 2^20 * K / wall-time / 1e6 Mscalar-mul/s,
 max wall-time over ranks, inputs resident in HBM when the timed region starts.
 `roofline` is for the dominant kernel (level-1 bucket accumulation): algorithmic bytes
 (128 B per scalar-mul) / its HIP-event duration, against the 8 TB/s HBM peak.
