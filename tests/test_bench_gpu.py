@@ -25,3 +25,18 @@ def test_bench_two_ranks_on_one_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and d["unit"] == "Mscalar-mul/s"
     assert d["value"] > 0 and d["cpu_baseline"] is None and d["roofline"]["bound"] == "hbm"
     assert "x2" in d["config"]["parallelism"]
+
+
+@pytest.mark.parametrize("schedule", ["pipeline", "streams"])
+def test_bench_single_gpu_contract_and_parity(schedule):
+    # bench.py asserts GPU bytes == C oracle bytes on its own inputs (cpu_baseline leg) in both schedules
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "1", "--logn", "16",
+                          "--schedule", schedule], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["vs_baseline"] is None and d["config"]["schedule"] == schedule
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["value"] > 0
