@@ -75,7 +75,7 @@ static MsmPlan make_plan(int n) {
   p.LK = env_int("OZK_MSM_LK", 16);
   if (p.L1 < 2) p.L1 = 2;
   if (p.LK < 4) p.LK = 4;
-  int S = env_int("OZK_MSM_S", 8);
+  int S = env_int("OZK_MSM_S", 4);
   int sg = ilog2((uint32_t)(S < 2 ? 2 : S));
   p.S = 1 << sg;
   return p;
@@ -191,15 +191,14 @@ size_t tail_layout(const MsmPlan& p, MsmLayout& L, void* tail, size_t tail_bytes
   return b.off;
 }
 
-// First window-sum level.  Fused form (default): a lane sums S = 8 buckets, its wave combines the 64
-// lane results in registers -> W * 2^cb / 512 elements.  Everything after the bucket accumulation is
+// First window-sum level.  Fused form (default): a lane sums S = 4 buckets, its wave combines the 64
+// lane results in registers -> W * 2^cb / 256 elements.  Everything after the bucket accumulation is
 // multiplier-issue work spread over few waves, so WHERE it runs matters more than how deep it is
 // (measured at 2^20 with unsigned digits, two MSMs in flight, Mscalar-mul/s / single-MSM ms):
 //     unfused S=16, closing the head phase                      444-447 / 3.40-3.44
 //     fused S=4, opening the tail phase, no issue priority      461-465 / 3.48-3.64
 //     fused S=16 / unfused S=8 in the tail, with or without priority: 372-420 (their 512-1024 waves
 //     sit on the same SIMDs as the next MSM's bucket accumulation and stretch it 1.35 -> 1.5-1.9 ms)
-// (S = 8 became the default later, together with the early order event, see var_msm_tail.)
 static bool wsum0_in_tail() { return env_int("OZK_MSM_WSUM0_IN_TAIL", 1) != 0; }
 static bool wsum_fused() { return env_int("OZK_MSM_WSUM_FUSED", 1) != 0; }
 // elements per window the first level leaves, and the g (log2 of buckets per element) they carry
@@ -409,11 +408,12 @@ int var_msm_tail(int n, void* tail, size_t tail_bytes, void* d_out, hipStream_t 
   int fin_max = env_int("OZK_MSM_FIN_MAX", 4);
   if (fin_max < 1) fin_max = 1;
   if (fin_max > 16) fin_max = 16;
-  // The order event is recorded after the FIRST window-sum level (1024 waves); with S = 8 the wave level
-  // behind it is 8 waves, which find a free slot beside the next accumulation (it keeps one per SIMD
-  // free) and hardly disturb it.  Measured against "S = 4, event after the wave level": 485-489 vs
-  // 475-479 Mscalar-mul/s two in flight, 3.31-3.35 vs 3.43-3.49 ms single.
-  const bool order_early = env_int("OZK_MSM_ORDER_EARLY", 1) != 0;
+  // OZK_MSM_ORDER_EARLY=1 records the order event after the FIRST window-sum level instead; with
+  // OZK_MSM_S=8 the wave level behind it is 8 waves, which find a free slot beside the next accumulation
+  // (it keeps one per SIMD free).  Measured against the default (S = 4, event after the wave level): the
+  // same throughput (481-489 vs 475-485 Mscalar-mul/s), a shorter single MSM (3.30 vs 3.43 ms), but the
+  // accumulation kernel itself stretched from 1.40 to 1.50 ms by the overlap — not the default.
+  const bool order_early = env_int("OZK_MSM_ORDER_EARLY", 0) != 0;
   if (order_ev && order_early) OZK_HIP(hipEventRecord(order_ev, st));
   while (m_in > fin_max) {
     const int m_out = (m_in + 63) / 64;
