@@ -740,6 +740,8 @@ struct RunAcc<CV, true> {
   __device__ __forceinline__ void accumulate(const u32* pts, const u32* idx, long long p) {
     a = xyzz_madd(a, load_signed(pts, idx, p));
   }
+  __device__ __forceinline__ void start_q(const Aff<EA>& q) { a = xyzz_from_affine<CV>(q); }
+  __device__ __forceinline__ void accumulate_q(const Aff<EA>& q) { a = xyzz_madd(a, q); }
   __device__ __forceinline__ void store(u32* dst) const { IO::store_rec_xyzz(a, dst); }
   // neutral element in the XYZZ record format (chunk cut on both sides)
   __device__ __forceinline__ void store_infinity(u32* dst) const {
@@ -884,6 +886,36 @@ segreduce_lane(const int t, const u32* __restrict__ bid_in, const u32* __restric
       extern __shared__ u32 ozk_acc_lds[];
       acc.init(ozk_acc_lds);
     }
+    if constexpr (FIRST && !CV::LDS_ACC) {
+      // level 1 in registers: the next entry's (bucket id, base) gather is issued one addition ahead,
+      // so the dependent idx -> base load chain overlaps the ~12 multiplications of the current one
+      // (every entry of the sorted array is a live base index at this level)
+      u32 nb = first_bid;
+      auto nq = Acc::load_signed(pts_in, idx_in, s);
+      for (long long p = s; p < e; p++) {
+        const u32 b = nb;
+        const auto q = nq;
+        if (p + 1 < e) {
+          nb = bid_in[p + 1];
+          nq = Acc::load_signed(pts_in, idx_in, p + 1);
+        }
+        if (b != cur) {
+          if (cur != BID_NONE) {
+            if (cur_cb) {
+              head_bid = cur;
+              acc.store(pts_out + (size_t)(2 * (size_t)t) * IO::REC_WORDS);
+            } else {
+              acc.store(buckets + (size_t)cur * IO::REC_WORDS);
+            }
+          }
+          cur = b;
+          cur_cb = (p == s) && cb;
+          acc.start_q(q);
+        } else {
+          acc.accumulate_q(q);
+        }
+      }
+    } else {
     for (long long p = s; p < e; p++) {
       const u32 b = bid_in[p];
       if (b != cur) {
@@ -901,6 +933,7 @@ segreduce_lane(const int t, const u32* __restrict__ bid_in, const u32* __restric
       } else if (b != BID_NONE) {
         acc.accumulate(pts_in, idx_in, p);
       }
+    }
     }
     if (cur != BID_NONE) {  // last run of the chunk
       if (cur_cb) {
