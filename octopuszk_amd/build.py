@@ -49,7 +49,7 @@ def build(force=False, verbose=True):
         # one object per translation unit, compiled in parallel, then one device link
         objdir = os.path.join(HERE, "_obj")
         os.makedirs(objdir, exist_ok=True)
-        common = [hipcc(), "-std=c++17", "-O3", "--offload-arch=gfx950", "-fPIC", "-fgpu-rdc" if False else "-fno-gpu-rdc",
+        common = [hipcc(), "-std=c++17", "-O3", "--offload-arch=gfx950", "-fPIC", "-fno-gpu-rdc",
                   "-Wno-unused-result", "-Wno-pass-failed"] + defs
         procs, objs = [], []
         for src in srcs:
