@@ -90,20 +90,22 @@ OZK_HD bool is_zero(const Fe2<B>& a) {  // Fp2.java:78-80
   return is_zero(a.c0) && is_zero(a.c1);
 }
 
-constexpr bool kara_ok(int B1, int B2) { return 4LL * B1 * B2 <= (long long)MONT_SLACK * 256; }
+// bounds for which a0 b0 + (-a1) b1 (the larger of the two dual products) meets the Montgomery precondition
+constexpr bool lazy_ok(int B1, int B2) {
+  return (long long)B1 * B2 + 16LL * (B1 / 16 + 1) * B2 <= (long long)MONT_SLACK * 256;
+}
 
-// (a0 + a1 u)(b0 + b1 u) = (a0b0 - a1b1) + ((a0+a1)(b0+b1) - a0b0 - a1b1) u   (Fp2.java:59-72)
+// (a0 + a1 u)(b0 + b1 u) = (a0 b0 - a1 b1) + (a0 b1 + a1 b0) u.  Same values as Fp2.java:59-72 (which
+// uses Karatsuba); here each component is ONE lazily reduced dual product (fp29.cuh mul2), which is
+// fewer instructions than three single products plus Karatsuba's additions on this multiplier.
 template <int B1, int B2>
 OZK_HD Fe2<32> mul(const Fe2<B1>& a_in, const Fe2<B2>& b_in) {
-  if constexpr (!kara_ok(B1, B2)) {
+  if constexpr (!lazy_ok(B1, B2)) {
     return mul(reduce_to<(B1 > 32 ? 32 : B1)>(a_in), reduce_to<(B2 > 32 ? 32 : B2)>(b_in));
   } else {
-    const auto v0 = mul(a_in.c0, b_in.c0);
-    const auto v1 = mul(a_in.c1, b_in.c1);
-    const auto s = mul(add(a_in.c0, a_in.c1), add(b_in.c0, b_in.c1));
     Fe2<32> r;
-    r.c0 = Fe<FqParams, 32>(reduce_to<32>(sub(v0, v1)));
-    r.c1 = Fe<FqParams, 32>(reduce_to<32>(sub(s, add(v0, v1))));
+    r.c0 = Fe<FqParams, 32>(mul2(a_in.c0, b_in.c0, neg(a_in.c1), b_in.c1));
+    r.c1 = Fe<FqParams, 32>(mul2(a_in.c0, b_in.c1, a_in.c1, b_in.c0));
     return r;
   }
 }
@@ -333,21 +335,21 @@ __device__ __forceinline__ Fe2L<32> sqr(const Fe2L<B1>& a_in) {
     return r;
   }
 }
-// lane 0: a0 b0, lane 1: a1 b1, then both: (a0 + a1)(b0 + b1)
+// lane 0 of the pair: a0 b0 + (-a1) b1; lane 1: a0 b1 + a1 b0 (one dual product each, then exchange)
 template <int B1, int B2>
 __device__ __forceinline__ Fe2L<32> mul(const Fe2L<B1>& a_in, const Fe2L<B2>& b_in) {
-  if constexpr (!kara_ok(B1, B2)) {
+  if constexpr (!lazy_ok(B1, B2)) {
     return mul(reduce_to<(B1 > 32 ? 32 : B1)>(a_in), reduce_to<(B2 > 32 ? 32 : B2)>(b_in));
   } else {
     const bool odd = (threadIdx.x & 1) != 0;
-    const auto p = mul(select_el(odd, a_in.c1, a_in.c0), select_el(odd, b_in.c1, b_in.c0));
+    const auto na1 = neg(a_in.c1);
+    using TN = std::decay_t<decltype(na1)>;
+    const auto p = mul2(a_in.c0, select_el(odd, b_in.c1, b_in.c0),
+                        select_el(odd, TN(a_in.c1), na1), select_el(odd, b_in.c0, b_in.c1));
     const auto q = shfl_xor_el(p, 1);
-    const auto v0 = select_el(odd, q, p);
-    const auto v1 = select_el(odd, p, q);
-    const auto s = mul(add(a_in.c0, a_in.c1), add(b_in.c0, b_in.c1));
     Fe2L<32> r;
-    r.c0 = Fe<FqParams, 32>(reduce_to<32>(sub(v0, v1)));
-    r.c1 = Fe<FqParams, 32>(reduce_to<32>(sub(s, add(v0, v1))));
+    r.c0 = Fe<FqParams, 32>(select_el(odd, q, p));
+    r.c1 = Fe<FqParams, 32>(select_el(odd, p, q));
     return r;
   }
 }
