@@ -117,7 +117,7 @@ OZK_HD Jac<CV> jac_madd(const Jac<CV>& p, const Aff<typename CV::EA>& q) {
   const auto r = dbl(rh);
   const auto V = mul(p.X, I);
   const auto X3 = sub(sqr(r), add(J, dbl(V)));
-  const auto Y3 = sub(mul(r, sub(V, X3)), dbl(mul(p.Y, J)));
+  const auto Y3 = mulsub(r, sub(V, X3), dbl(p.Y), J);
   const auto Z3 = sub(sqr(add(p.Z, H)), add(Z1Z1, HH));
   Jac<CV> out;
   out.X = typename CV::EX(X3);
@@ -169,7 +169,7 @@ OZK_HD Xyzz<CV> xyzz_dbl_affine(const Aff<typename CV::EA>& q) {
   const auto xx = sqr(q.x);
   const auto M = add(dbl(xx), xx);
   const auto X3 = sub(sqr(M), dbl(S));
-  const auto Y3 = sub(mul(M, sub(S, X3)), mul(W, q.y));
+  const auto Y3 = mulsub(M, sub(S, X3), W, q.y);
   Xyzz<CV> r;
   r.X = typename CV::XX(X3);
   r.Y = typename CV::XY(Y3);
@@ -198,7 +198,7 @@ OZK_HD Xyzz<CV> xyzz_madd(const Xyzz<CV>& p, const Aff<typename CV::EA>& q) {
   const auto PPP = mul(P, PP);
   const auto Q = mul(p.X, PP);
   const auto X3 = sub(sqr(R), add(PPP, dbl(Q)));
-  const auto Y3 = sub(mul(R, sub(Q, X3)), mul(p.Y, PPP));
+  const auto Y3 = mulsub(R, sub(Q, X3), p.Y, PPP);
   Xyzz<CV> out;
   out.X = typename CV::XX(X3);
   out.Y = typename CV::XY(Y3);
@@ -218,7 +218,7 @@ OZK_HD Xyzz<CV> xyzz_dbl(const Xyzz<CV>& p) {
   const auto xx = sqr(p.X);
   const auto M = add(dbl(xx), xx);
   const auto X3 = sub(sqr(M), dbl(S));
-  const auto Y3 = sub(mul(M, sub(S, X3)), mul(W, p.Y));
+  const auto Y3 = mulsub(M, sub(S, X3), W, p.Y);
   Xyzz<CV> r;
   r.X = typename CV::XX(X3);
   r.Y = typename CV::XY(Y3);
@@ -250,7 +250,7 @@ OZK_HD Xyzz<CV> xyzz_add(const Xyzz<CV>& p, const Xyzz<CV>& q) {
   const auto PPP = mul(P, PP);
   const auto Q = mul(U1, PP);
   const auto X3 = sub(sqr(R), add(PPP, dbl(Q)));
-  const auto Y3 = sub(mul(R, sub(Q, X3)), mul(S1, PPP));
+  const auto Y3 = mulsub(R, sub(Q, X3), S1, PPP);
   Xyzz<CV> out;
   out.X = typename CV::XX(X3);
   out.Y = typename CV::XY(Y3);
@@ -293,7 +293,7 @@ OZK_HD Jac<CV> jac_add(const Jac<CV>& p, const Jac<CV>& q) {
   const auto r = dbl(rh);
   const auto V = mul(U1, I);
   const auto X3 = sub(sqr(r), add(J, dbl(V)));
-  const auto Y3 = sub(mul(r, sub(V, X3)), dbl(mul(S1, J)));
+  const auto Y3 = mulsub(r, sub(V, X3), dbl(S1), J);
   const auto Z3 = mul(sub(sqr(add(Z1, Z2)), add(Z1Z1, Z2Z2)), H);
   Jac<CV> out;
   out.X = typename CV::EX(X3);

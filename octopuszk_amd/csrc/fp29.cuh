@@ -152,6 +152,50 @@ OZK_HD auto mul2(const Fe<P, B1>& a, const Fe<P, B2>& b, const Fe<P, B3>& c, con
   return r;
 }
 
+// a*b + c*d + e*f + g*h with one reduction (36 + 9 products of < 2^58 plus the carry: < 2^63.6).
+// Two of these make an Fq2 "a b - c d" (fq2.cuh mulsub).
+template <class P, int B1, int B2, int B3, int B4, int B5, int B6, int B7, int B8>
+OZK_HD auto mul4(const Fe<P, B1>& a, const Fe<P, B2>& b, const Fe<P, B3>& c, const Fe<P, B4>& d,
+                 const Fe<P, B5>& e, const Fe<P, B6>& f, const Fe<P, B7>& g, const Fe<P, B8>& h) {
+  constexpr long long BB = (long long)B1 * B2 + (long long)B3 * B4 + (long long)B5 * B6 + (long long)B7 * B8;
+  static_assert(BB <= (long long)MONT_SLACK * 256, "Montgomery input bounds too large");
+  constexpr int BO = 16 + ceil_div(BB, 16 * MONT_SLACK);
+  Fe<P, BO> r;
+  u32 m[9];
+  u64 acc = 0;
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+#pragma unroll
+    for (int i = 0; i <= k; i++) {
+      acc = mad64(a.l[i], b.l[k - i], acc);
+      acc = mad64(c.l[i], d.l[k - i], acc);
+      acc = mad64(e.l[i], f.l[k - i], acc);
+      acc = mad64(g.l[i], h.l[k - i], acc);
+    }
+#pragma unroll
+    for (int i = 0; i < k; i++) acc = mad64(m[i], P::P[k - i], acc);
+    m[k] = ((u32)acc * P::PINV) & FE_MASK;
+    acc = mad64(m[k], P::P[0], acc);
+    acc >>= FE_W;
+  }
+#pragma unroll
+  for (int k = 9; k < 17; k++) {
+#pragma unroll
+    for (int i = k - 8; i < 9; i++) {
+      acc = mad64(a.l[i], b.l[k - i], acc);
+      acc = mad64(c.l[i], d.l[k - i], acc);
+      acc = mad64(e.l[i], f.l[k - i], acc);
+      acc = mad64(g.l[i], h.l[k - i], acc);
+    }
+#pragma unroll
+    for (int i = k - 8; i < 9; i++) acc = mad64(m[i], P::P[k - i], acc);
+    r.l[k - 9] = (u32)acc & FE_MASK;
+    acc >>= FE_W;
+  }
+  r.l[8] = (u32)acc;
+  return r;
+}
+
 // c ? a : b, limb-wise (v_cndmask)
 template <class P, int B>
 OZK_HD Fe<P, B> select_el(bool c, const Fe<P, B>& a, const Fe<P, B>& b) {
@@ -239,6 +283,17 @@ OZK_HD auto neg(const Fe<P, B2>& b) {
   for (int i = 0; i < 9; i++) r.l[i] = P::BIAS[K][i] - b.l[i];
   fe_carry(r);
   return r;
+}
+
+// a*b - c*d: one dual product on (a, b, -c, d) when the bounds allow, i.e. one reduction and no
+// subtraction of the two reduced products (the Y3 of every addition / doubling formula in ec.cuh)
+template <class P, int B1, int B2, int B3, int B4>
+OZK_HD auto mulsub(const Fe<P, B1>& a, const Fe<P, B2>& b, const Fe<P, B3>& c, const Fe<P, B4>& d) {
+  if constexpr ((long long)B1 * B2 + 16LL * (B3 / 16 + 1) * B4 <= (long long)MONT_SLACK * 256) {
+    return mul2(a, b, neg(c), d);
+  } else {
+    return sub(mul(a, b), mul(c, d));
+  }
 }
 
 // if (a >= K*p) a -= K*p          (branch-free, signed borrow propagation)

@@ -109,6 +109,27 @@ OZK_HD Fe2<32> mul(const Fe2<B1>& a_in, const Fe2<B2>& b_in) {
     return r;
   }
 }
+// a b - c d over Fq2: each component is one four-term product sum
+//   c0 = a0 b0 + (-a1) b1 + (-c0) d0 + c1 d1,   c1 = a0 b1 + a1 b0 + (-c0) d1 + (-c1) d0
+template <int B1, int B2, int B3, int B4>
+OZK_HD auto mulsub(const Fe2<B1>& a, const Fe2<B2>& b, const Fe2<B3>& c, const Fe2<B4>& d) {
+  constexpr long long N1 = 16LL * (B1 / 16 + 1), N3 = 16LL * (B3 / 16 + 1);
+  constexpr long long BB0 = (long long)B1 * B2 + N1 * B2 + N3 * B4 + (long long)B3 * B4;
+  constexpr long long BB1 = 2LL * B1 * B2 + 2 * N3 * B4;
+  constexpr long long BB = BB0 > BB1 ? BB0 : BB1;
+  if constexpr (BB <= (long long)MONT_SLACK * 256) {
+    constexpr int BO = 16 + ceil_div(BB, 16 * MONT_SLACK);
+    const auto na1 = neg(a.c1);
+    const auto nc0 = neg(c.c0);
+    const auto nc1 = neg(c.c1);
+    Fe2<BO> r;
+    r.c0 = Fe<FqParams, BO>(mul4(a.c0, b.c0, na1, b.c1, nc0, d.c0, c.c1, d.c1));
+    r.c1 = Fe<FqParams, BO>(mul4(a.c0, b.c1, a.c1, b.c0, nc0, d.c1, nc1, d.c0));
+    return r;
+  } else {
+    return sub(mul(a, b), mul(c, d));
+  }
+}
 template <int B>
 OZK_HD Fe2<B> select_el(bool c, const Fe2<B>& a, const Fe2<B>& b) {
   Fe2<B> r;
@@ -352,6 +373,10 @@ __device__ __forceinline__ Fe2L<32> mul(const Fe2L<B1>& a_in, const Fe2L<B2>& b_
     r.c1 = Fe<FqParams, 32>(select_el(odd, p, q));
     return r;
   }
+}
+template <int B1, int B2, int B3, int B4>
+__device__ __forceinline__ auto mulsub(const Fe2L<B1>& a, const Fe2L<B2>& b, const Fe2L<B3>& c, const Fe2L<B4>& d) {
+  return sub(mul(a, b), mul(c, d));
 }
 struct G2CfgL {
   using EX = Fe2L<144>;

@@ -820,7 +820,7 @@ struct RunAccLds {
     const auto X3 = sub(sqr(R), add(PPP, dbl(Q)));
     st(0, typename CV::XX(X3));
     asm volatile("" ::: "memory");
-    const auto Y3 = sub(mul(R, sub(Q, X3)), mul(ld<typename CV::XY>(1), PPP));
+    const auto Y3 = mulsub(R, sub(Q, X3), ld<typename CV::XY>(1), PPP);
     st(1, typename CV::XY(Y3));
   }
   __device__ __forceinline__ Xyzz<CV> get() const {

@@ -100,6 +100,12 @@ extern "C" void hc_fq2_op(int op, const u32* a, const u32* b, u32* out) {  // 16
     case 3: ElemTraits<Fe2<49>>::to_wire(sub(x, y), out); break;
     case 4: ElemTraits<Fe2<32>>::to_wire(inv(x), out); break;
     case 5: { auto big = sub(dbl(dbl(x)), y); ElemTraits<Fe2<32>>::to_wire(mul(big, big), out); break; }
+    case 6: {  // a b - c d as two four-term product sums, with unreduced inputs
+      auto big = sub(dbl(dbl(x)), y);
+      auto r = mulsub(x, big, add(x, y), y);
+      ElemTraits<Fe2<32>>::to_wire(Fe2<32>(reduce_to<32>(r)), out);
+      break;
+    }
     default: break;
   }
 }

@@ -169,6 +169,7 @@ def test_fq2_ops(hc):
         assert fq2_op(hc, 3, a, b) == F.sub(a, b)
         big = F.sub(F.add(F.add(a, a), F.add(a, a)), b)
         assert fq2_op(hc, 5, a, b) == F.mul(big, big)
+        assert fq2_op(hc, 6, a, b) == F.sub(F.mul(a, big), F.mul(F.add(a, b), b))
         if a != (0, 0):
             assert fq2_op(hc, 4, a) == F.inv(a)
 
