@@ -150,11 +150,11 @@ OZK_HD Fe2<32> sqr(const Fe2<B1>& a_in) {
   if constexpr (B1 > 32) {
     return sqr(reduce_to<32>(a_in));
   } else {
-    const auto t = mul(a_in.c0, a_in.c1);
+    const auto t = mul(dbl(a_in.c0), a_in.c1);  // doubling an input keeps the product < 2p: no conditional subtraction
     const auto d = mul(add(a_in.c0, a_in.c1), sub(a_in.c0, a_in.c1));
     Fe2<32> r;
     r.c0 = Fe<FqParams, 32>(reduce_to<32>(d));
-    r.c1 = Fe<FqParams, 32>(reduce_to<32>(dbl(t)));
+    r.c1 = Fe<FqParams, 32>(reduce_to<32>(t));
     return r;
   }
 }
@@ -333,7 +333,7 @@ template <int B>
 __device__ __forceinline__ bool is_zero(const Fe2L<B>& a) {
   return is_zero(a.c0) && is_zero(a.c1);
 }
-// lane 0 of the pair: (a0 + a1)(a0 - a1); lane 1: a0 a1
+// lane 0 of the pair: (a0 + a1)(a0 - a1); lane 1: a0 (2 a1)
 template <int B1>
 __device__ __forceinline__ Fe2L<32> sqr(const Fe2L<B1>& a_in) {
   if constexpr (B1 > 32) {
@@ -345,14 +345,14 @@ __device__ __forceinline__ Fe2L<32> sqr(const Fe2L<B1>& a_in) {
     using TS = std::decay_t<decltype(s)>;
     using TD = std::decay_t<decltype(d)>;
     const TS x = select_el(odd, TS(a_in.c0), s);
-    const TD y = select_el(odd, TD(a_in.c1), d);
+    const TD y = select_el(odd, TD(dbl(a_in.c1)), d);
     const auto p = mul(x, y);
     const auto q = shfl_xor_el(p, 1);
     const auto t0 = select_el(odd, q, p);  // (a0 + a1)(a0 - a1)
-    const auto t1 = select_el(odd, p, q);  // a0 a1
+    const auto t1 = select_el(odd, p, q);  // 2 a0 a1
     Fe2L<32> r;
     r.c0 = Fe<FqParams, 32>(reduce_to<32>(t0));
-    r.c1 = Fe<FqParams, 32>(reduce_to<32>(dbl(t1)));
+    r.c1 = Fe<FqParams, 32>(reduce_to<32>(t1));
     return r;
   }
 }
