@@ -786,12 +786,18 @@ struct RunAccLds {
     st(2, a.ZZ);
     st(3, a.ZZZ);
   }
-  __device__ __forceinline__ void start(const u32* pts, const u32* idx, long long p) {
-    put(xyzz_from_affine<CV>(RunAcc<CV, true>::load_signed(pts, idx, p)));
+  static __device__ __forceinline__ Aff<EA> load_signed(const u32* pts, const u32* idx, long long p) {
+    return RunAcc<CV, true>::load_signed(pts, idx, p);
   }
-  // madd-2008-s, staged over the LDS-resident accumulator
+  __device__ __forceinline__ void start(const u32* pts, const u32* idx, long long p) {
+    start_q(load_signed(pts, idx, p));
+  }
   __device__ __forceinline__ void accumulate(const u32* pts, const u32* idx, long long p) {
-    const Aff<EA> q = RunAcc<CV, true>::load_signed(pts, idx, p);
+    accumulate_q(load_signed(pts, idx, p));
+  }
+  __device__ __forceinline__ void start_q(const Aff<EA>& q) { put(xyzz_from_affine<CV>(q)); }
+  // madd-2008-s, staged over the LDS-resident accumulator
+  __device__ __forceinline__ void accumulate_q(const Aff<EA>& q) {
     if (is_inf(q)) return;
     const auto ZZ = ld<typename CV::XZZ>(2);
     if (is_zero(ZZ)) {  // accumulator at infinity
@@ -886,8 +892,8 @@ segreduce_lane(const int t, const u32* __restrict__ bid_in, const u32* __restric
       extern __shared__ u32 ozk_acc_lds[];
       acc.init(ozk_acc_lds);
     }
-    if constexpr (FIRST && !CV::LDS_ACC) {
-      // level 1 in registers: the next entry's (bucket id, base) gather is issued one addition ahead,
+    if constexpr (FIRST) {
+      // level 1: the next entry's (bucket id, base) gather is issued one addition ahead,
       // so the dependent idx -> base load chain overlaps the ~12 multiplications of the current one
       // (every entry of the sorted array is a live base index at this level)
       u32 nb = first_bid;
