@@ -206,6 +206,95 @@ __global__ void __launch_bounds__(256) k_fb_norm(const u32* __restrict__ jac, in
   }
 }
 
+// The GLV gather-add over an AFFINE table: lane t normalises FB_BATCH consecutive table entries with one
+// shared inversion (k_fb_table_affine), after which every gather is a mixed XYZZ addition (madd-2008-s,
+// 8M + 2S) instead of a full Jacobian one (11M + 5S); 16 gathers per scalar against ~16 multiplications
+// per table entry for the normalisation.  Infinity entries (entry 0 of every window; every entry when the
+// base is infinity) become the (0, 0) marker.
+template <class CV>
+__global__ void __launch_bounds__(256) k_fb_table_affine(const u32* __restrict__ jac, int n, u32* __restrict__ aff) {
+  using IO = CurveIO<CV>;
+  using EA = typename CV::EA;
+  using EZ32 = decltype(reduce_to<32>(typename CV::EZ()));
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lo = t * FB_BATCH;
+  if (lo >= n) return;
+  const int cnt = (n - lo < FB_BATCH) ? (n - lo) : FB_BATCH;
+  EZ32 prefix[FB_BATCH];
+  EZ32 run = EZ32(el_one(prefix[0]));
+#pragma unroll
+  for (int k = 0; k < FB_BATCH; k++) {
+    if (k < cnt) {
+      const auto Z = reduce_to<32>(ElemTraits<typename CV::EZ>::load_raw(jac + (size_t)(lo + k) * IO::JAC_WORDS + 2 * IO::RW));
+      if (!is_zero(Z)) run = EZ32(mul(run, Z));
+    }
+    prefix[k] = run;
+  }
+  EZ32 invrun = EZ32(inv(run));
+#pragma unroll
+  for (int k = FB_BATCH - 1; k >= 0; k--) {
+    if (k < cnt) {
+      const Jac<CV> p = IO::load_jac(jac + (size_t)(lo + k) * IO::JAC_WORDS);
+      const auto Z = reduce_to<32>(p.Z);
+      Aff<EA> q;
+      if (is_zero(Z)) {
+        q.x = EA(el_zero(p.X));
+        q.y = EA(el_zero(p.X));
+      } else {
+        EZ32 zi = invrun;
+        if (k > 0) zi = EZ32(mul(invrun, prefix[k - 1]));
+        invrun = EZ32(mul(invrun, Z));
+        const auto zi2 = sqr(zi);
+        q.x = EA(reduce_to<17>(mul(p.X, zi2)));
+        q.y = EA(reduce_to<17>(mul(p.Y, mul(zi2, zi))));
+      }
+      IO::store_aff(q, aff + (size_t)(lo + k) * IO::AFF_WORDS);
+    }
+  }
+}
+
+template <class CV>
+__global__ void __launch_bounds__(256) k_fb_main_glv_affine(const u32* __restrict__ scalars, const u32* __restrict__ aff,
+                                                            int n, int oc, int ws, u32* __restrict__ jac_out) {
+  using IO = CurveIO<CV>;
+  using EA = typename CV::EA;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 s[8];
+  const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
+  const uint4 a = sp[0], b = sp[1];
+  s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w;
+  s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+  u32 k1[4], k2[4];
+  bool n1, n2;
+  glv_decompose(s, k1, n1, k2, n2);
+  Aff<EA> inf;
+  inf.x = EA(el_zero(inf.x));
+  inf.y = EA(el_zero(inf.x));
+  Xyzz<CV> part[2];
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const u32* k = h ? k2 : k1;
+    Xyzz<CV> acc = xyzz_from_affine<CV>(inf);
+    for (int w = 0; w < oc; w++) {
+      const int bit = w * ws;
+      u32 d = 0;
+      if (bit < 128) {
+        const int wi = bit >> 5, sh = bit & 31;
+        unsigned long long v = k[wi];
+        if (wi + 1 < 4) v |= (unsigned long long)k[wi + 1] << 32;
+        d = (u32)(v >> sh) & ((1u << ws) - 1u);
+      }
+      if (d != 0) acc = xyzz_madd(acc, IO::load_aff(aff + (((size_t)w << ws) + d) * IO::AFF_WORDS));
+    }
+    if (h ? n2 : n1) acc.Y = typename CV::XY(reduce_to<32>(neg(reduce_to<32>(acc.Y))));
+    part[h] = acc;
+  }
+  // phi(x, y) = (beta x, y): X -> beta X in XYZZ as well
+  part[1].X = typename CV::XX(reduce_to<32>(scale(part[1].X, glv_beta_fixed<CV>())));
+  IO::store_jac(xyzz_to_jac(xyzz_add(part[0], part[1])), jac_out + (size_t)i * IO::JAC_WORDS);
+}
+
 // x_i * b mod r, 64-byte big-endian out (field_MSM, FixedBaseMSM.cu:1241-1266)
 __global__ void __launch_bounds__(256) k_field_mul(const u32* __restrict__ in, int n, u32* __restrict__ out) {
   using ET = ElemTraits<Fe<FrParams, 17>>;
@@ -217,7 +306,7 @@ __global__ void __launch_bounds__(256) k_field_mul(const u32* __restrict__ in, i
 }
 
 struct FbLayout {
-  u32 *D, *table, *jac;
+  u32 *D, *table, *aff, *jac;
   size_t bytes;
 };
 template <class CV>
@@ -227,6 +316,7 @@ static FbLayout fb_layout(int outerc, int ws, int n, void* wsp, size_t wsb) {
   Bump b(wsp, wsb);
   L.D = b.take<u32>((size_t)outerc * ws * IO::JAC_WORDS);
   L.table = b.take<u32>(((size_t)outerc << ws) * IO::JAC_WORDS);
+  L.aff = b.take<u32>(((size_t)outerc << ws) * IO::AFF_WORDS);  // the table again, affine (GLV form)
   L.jac = b.take<u32>((size_t)n * IO::JAC_WORDS);
   b.take<u32>(64);
   L.bytes = b.off;
@@ -258,7 +348,13 @@ static int fixed_batch_dev(int outerc, int ws, int n, const void* d_base, const 
     const int tot = oc << k;
     hipLaunchKernelGGL((k_fb_level<CV>), dim3((tot + TB - 1) / TB), dim3(TB), 0, st, L.table, L.D, oc, ws, k);
   }
-  if (glv)
+  if (glv && env_int("OZK_FB_AFFINE", 1) != 0) {
+    const int entries = oc << ws;
+    const int tl = (entries + FB_BATCH - 1) / FB_BATCH;
+    hipLaunchKernelGGL((k_fb_table_affine<CV>), dim3((tl + TB - 1) / TB), dim3(TB), 0, st, L.table, entries, L.aff);
+    hipLaunchKernelGGL((k_fb_main_glv_affine<CV>), dim3((n + TB - 1) / TB), dim3(TB), 0, st, (const u32*)d_scalars,
+                       L.aff, n, oc, ws, L.jac);
+  } else if (glv)
     hipLaunchKernelGGL((k_fb_main_glv<CV>), dim3((n + TB - 1) / TB), dim3(TB), 0, st, (const u32*)d_scalars, L.table,
                        n, oc, ws, L.jac);
   else

@@ -50,6 +50,21 @@ def test_fixed_base_glv_edge_scalars():
             assert P == C.to_affine(C.mul(base, s_)), hex(s_)
 
 
+def test_fixed_base_infinity_base_and_small_orders():
+    # every table entry is the point at infinity: the affine table (msm_fixed.hip k_fb_table_affine) must carry
+    # the (0, 0) marker through the shared inversion; and scalars whose halves hit one window only
+    from octopuszk_amd import fixed_base_msm as fb
+    scalars = [0, 1, 5, o.R - 1, 1 << 130, (1 << 17) - 1, 1 << 17]
+    for C, is_g1 in ((o.G1, True), (o.G2, False)):
+        got = fb.batch_msm(254, 17, C.zero, scalars, is_g1=is_g1)
+        for P in got:
+            assert P == C.to_affine(C.zero)
+        base = C.mul(C.one, 3)
+        got = fb.batch_msm(254, 6, base, scalars, is_g1=is_g1)    # 22 windows of 6 bits per half
+        for s_, P in zip(scalars, got):
+            assert P == C.to_affine(C.mul(base, s_)), hex(s_)
+
+
 def test_fixed_base_truncates_to_outerc_windows():
     # only the first outerc windows of the scalar are used (FixedBaseMSM.java:146-164)
     from octopuszk_amd import fixed_base_msm as fb
