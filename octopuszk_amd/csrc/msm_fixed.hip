@@ -26,6 +26,7 @@
 //                 big-endian stores
 #include "fq2.cuh"
 #include "glv.cuh"
+#include "msm_var.cuh"  // RunAccLds: the LDS-resident XYZZ accumulator (G2)
 #include "ozk_common.h"
 
 namespace ozk {
@@ -254,7 +255,7 @@ __global__ void __launch_bounds__(256) k_fb_table_affine(const u32* __restrict__
 }
 
 template <class CV>
-__global__ void __launch_bounds__(256) k_fb_main_glv_affine(const u32* __restrict__ scalars, const u32* __restrict__ aff,
+__global__ void __launch_bounds__(256, CV::LDS_ACC ? 2 : 1) k_fb_main_glv_affine(const u32* __restrict__ scalars, const u32* __restrict__ aff,
                                                             int n, int oc, int ws, u32* __restrict__ jac_out) {
   using IO = CurveIO<CV>;
   using EA = typename CV::EA;
@@ -275,7 +276,14 @@ __global__ void __launch_bounds__(256) k_fb_main_glv_affine(const u32* __restric
 #pragma unroll
   for (int h = 0; h < 2; h++) {
     const u32* k = h ? k2 : k1;
-    Xyzz<CV> acc = xyzz_from_affine<CV>(inf);
+    // G2: the accumulator lives in LDS (as in the variable-base level 1) — two waves per SIMD instead of one
+    using Acc = std::conditional_t<CV::LDS_ACC, RunAccLds<CV>, RunAcc<CV, true>>;
+    Acc acc;
+    if constexpr (CV::LDS_ACC) {
+      extern __shared__ u32 ozk_acc_lds[];
+      acc.init(ozk_acc_lds);
+    }
+    acc.start_q(inf);
     for (int w = 0; w < oc; w++) {
       const int bit = w * ws;
       u32 d = 0;
@@ -285,10 +293,13 @@ __global__ void __launch_bounds__(256) k_fb_main_glv_affine(const u32* __restric
         if (wi + 1 < 4) v |= (unsigned long long)k[wi + 1] << 32;
         d = (u32)(v >> sh) & ((1u << ws) - 1u);
       }
-      if (d != 0) acc = xyzz_madd(acc, IO::load_aff(aff + (((size_t)w << ws) + d) * IO::AFF_WORDS));
+      if (d != 0) acc.accumulate_q(IO::load_aff(aff + (((size_t)w << ws) + d) * IO::AFF_WORDS));
     }
-    if (h ? n2 : n1) acc.Y = typename CV::XY(reduce_to<32>(neg(reduce_to<32>(acc.Y))));
-    part[h] = acc;
+    Xyzz<CV> r;
+    if constexpr (CV::LDS_ACC) r = acc.get();
+    else r = acc.a;
+    if (h ? n2 : n1) r.Y = typename CV::XY(reduce_to<32>(neg(reduce_to<32>(r.Y))));
+    part[h] = r;
   }
   // phi(x, y) = (beta x, y): X -> beta X in XYZZ as well
   part[1].X = typename CV::XX(reduce_to<32>(scale(part[1].X, glv_beta_fixed<CV>())));
@@ -352,8 +363,12 @@ static int fixed_batch_dev(int outerc, int ws, int n, const void* d_base, const 
     const int entries = oc << ws;
     const int tl = (entries + FB_BATCH - 1) / FB_BATCH;
     hipLaunchKernelGGL((k_fb_table_affine<CV>), dim3((tl + TB - 1) / TB), dim3(TB), 0, st, L.table, entries, L.aff);
-    hipLaunchKernelGGL((k_fb_main_glv_affine<CV>), dim3((n + TB - 1) / TB), dim3(TB), 0, st, (const u32*)d_scalars,
-                       L.aff, n, oc, ws, L.jac);
+    const size_t acc_lds = CV::LDS_ACC ? (size_t)RunAccLds<CV>::LDS_WORDS * TB * sizeof(u32) : 0;  // 72 KiB for G2
+    if (acc_lds > 65536)
+      OZK_HIP(hipFuncSetAttribute((const void*)(k_fb_main_glv_affine<CV>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)acc_lds));
+    hipLaunchKernelGGL((k_fb_main_glv_affine<CV>), dim3((n + TB - 1) / TB), dim3(TB), acc_lds, st,
+                       (const u32*)d_scalars, L.aff, n, oc, ws, L.jac);
   } else if (glv)
     hipLaunchKernelGGL((k_fb_main_glv<CV>), dim3((n + TB - 1) / TB), dim3(TB), 0, st, (const u32*)d_scalars, L.table,
                        n, oc, ws, L.jac);
