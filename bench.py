@@ -47,8 +47,8 @@ def rand_scalars(n, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--logn", type=int, default=LOGN)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prepared", action="store_true",
@@ -60,7 +60,7 @@ def main():
                     help="pipeline (default): one head stream + one tail stream with the launch-order hint "
                          "(device.VarMsmPipeline) — the level-1 kernel runs alone, so its HIP-event duration is the "
                          "kernel's own; streams: complete MSMs issued round-robin on independent streams, the way "
-                         "concurrent prover threads drive the JNI — ~6 %% more throughput at 3 in flight (513-527 "
+                         "concurrent prover threads drive the JNI — ~6 %% more throughput at 3 in flight (540-550 "
                          "Mscalar-mul/s), but the overlapping level-1 kernels stretch each other's duration, which "
                          "would distort `roofline`")
     args = ap.parse_args()

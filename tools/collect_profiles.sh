@@ -7,8 +7,8 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/evidence
 rm -rf $O && mkdir -p $O
 cd $R
-python bench.py --steps 40 > $O/bench_default.json 2> $O/bench_default.err
-python bench.py --steps 40 --in-flight 1 --no-cpu-baseline > $O/bench_in_flight_1.json 2> $O/bench_in_flight_1.err
+python bench.py > $O/bench_default.json 2> $O/bench_default.err
+python bench.py --in-flight 1 --no-cpu-baseline > $O/bench_in_flight_1.json 2> $O/bench_in_flight_1.err
 python tools/perf_all.py > $O/perf_all.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $O/kt_default --output-format csv -- python3 $R/bench.py --no-cpu-baseline --steps 20 > $O/kt_default.log 2>&1
