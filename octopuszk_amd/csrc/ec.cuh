@@ -313,7 +313,7 @@ OZK_HD Jac<CV> jac_neg(const Jac<CV>& p) {
 struct G1Cfg {
   using Pair = G1Cfg;                     // serial chains run on one lane
   static constexpr int PAIR_LANES = 1;
-  static constexpr bool LDS_ACC = false;  // level-1 accumulator in registers (125 VGPRs, 4 waves per SIMD)
+  static constexpr bool LDS_ACC = false;  // level-1 accumulator in registers (137 VGPRs with the prefetched base, 3 waves per SIMD)
   using EX = Fe<FqParams, 94>;
   using EY = Fe<FqParams, 73>;
   using EZ = Fe<FqParams, 78>;
