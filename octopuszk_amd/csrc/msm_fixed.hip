@@ -351,16 +351,32 @@ static int fixed_batch_dev(int outerc, int ws, int n, const void* d_base, const 
   // GLV form when the caller's windows cover a whole Fr scalar (they always do in the reference:
   // outerc = ceil(scalarSize / windowSize), FixedBaseMSM.java:71-99); the plain form otherwise
   const bool glv = env_int("OZK_MSM_GLV", 1) != 0 && (long long)outerc * ws >= 254;
-  const int oc = glv ? (128 + ws - 1) / ws : outerc;
-  hipLaunchKernelGGL((k_fb_chain<CV>), dim3(1), dim3(64), 0, st, (const u32*)d_base, oc * ws, L.D);
+  // In the GLV form the table's window size is the library's choice (s B does not depend on it): the
+  // caller's (17 bits at 2^20) balances ONE 254-bit digit string against the table; with two 127-bit
+  // strings over one table a narrower window is cheaper.  Cost in multiplications: 2 ceil(128/w) mixed
+  // additions of ~10 per scalar + ~32 per table entry (level addition + normalisation).  Never wider
+  // than the caller's, so the workspace the caller sized always suffices.
+  int wt = ws;
+  if (glv) {
+    double best = 0;
+    for (int w = 1; w <= ws; w++) {
+      const double o = (128 + w - 1) / w;
+      const double cost = 2.0 * o * 10.0 * (double)n + o * 32.0 * (double)(1u << w);  // (the doubling chain is o w ~ 128 long either way)
+      if (w == 1 || cost < best) { best = cost; wt = w; }
+    }
+    wt = env_int("OZK_FB_WS", wt);
+    if (wt < 1 || wt > ws) wt = ws;
+  }
+  const int oc = glv ? (128 + wt - 1) / wt : outerc;
+  hipLaunchKernelGGL((k_fb_chain<CV>), dim3(1), dim3(64), 0, st, (const u32*)d_base, oc * wt, L.D);
   // entry 0 of every window is infinity: clear those records (all-zero Jacobian has Z = 0)
-  OZK_HIP(hipMemset2DAsync(L.table, ((size_t)1 << ws) * IO::JAC_WORDS * 4, 0, IO::JAC_WORDS * 4, oc, st));
-  for (int k = 0; k < ws; k++) {
+  OZK_HIP(hipMemset2DAsync(L.table, ((size_t)1 << wt) * IO::JAC_WORDS * 4, 0, IO::JAC_WORDS * 4, oc, st));
+  for (int k = 0; k < wt; k++) {
     const int tot = oc << k;
-    hipLaunchKernelGGL((k_fb_level<CV>), dim3((tot + TB - 1) / TB), dim3(TB), 0, st, L.table, L.D, oc, ws, k);
+    hipLaunchKernelGGL((k_fb_level<CV>), dim3((tot + TB - 1) / TB), dim3(TB), 0, st, L.table, L.D, oc, wt, k);
   }
   if (glv && env_int("OZK_FB_AFFINE", 1) != 0) {
-    const int entries = oc << ws;
+    const int entries = oc << wt;
     const int tl = (entries + FB_BATCH - 1) / FB_BATCH;
     hipLaunchKernelGGL((k_fb_table_affine<CV>), dim3((tl + TB - 1) / TB), dim3(TB), 0, st, L.table, entries, L.aff);
     const size_t acc_lds = CV::LDS_ACC ? (size_t)RunAccLds<CV>::LDS_WORDS * TB * sizeof(u32) : 0;  // 72 KiB for G2
@@ -368,10 +384,10 @@ static int fixed_batch_dev(int outerc, int ws, int n, const void* d_base, const 
       OZK_HIP(hipFuncSetAttribute((const void*)(k_fb_main_glv_affine<CV>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)acc_lds));
     hipLaunchKernelGGL((k_fb_main_glv_affine<CV>), dim3((n + TB - 1) / TB), dim3(TB), acc_lds, st,
-                       (const u32*)d_scalars, L.aff, n, oc, ws, L.jac);
+                       (const u32*)d_scalars, L.aff, n, oc, wt, L.jac);
   } else if (glv)
     hipLaunchKernelGGL((k_fb_main_glv<CV>), dim3((n + TB - 1) / TB), dim3(TB), 0, st, (const u32*)d_scalars, L.table,
-                       n, oc, ws, L.jac);
+                       n, oc, wt, L.jac);
   else
     hipLaunchKernelGGL((k_fb_main<CV>), dim3((n + TB - 1) / TB), dim3(TB), 0, st, (const u32*)d_scalars, L.table, n,
                        outerc, ws, L.jac);
