@@ -50,6 +50,9 @@ int ozk_version(void);
 /* number of visible HIP devices (0 if none); `taskID % count` selects the device as
  * the reference does (algebra_msm_VariableBaseMSM.cu:1249-1257). */
 int ozk_device_count(void);
+/* The OZK_* tuning environment variables are read once per process and cached (a plan must not change
+ * between the workspace-size query and the run); tests and tuning scripts call this after changing one. */
+int ozk_tuning_reload(void);
 
 /* ---------------- VariableBaseMSM ---------------------------------------
  * replaces Java_algebra_msm_VariableBaseMSM_variableBaseSerialMSMNativeHelper
@@ -85,6 +88,10 @@ int ozk_var_msm_dev(const void* d_bases, const void* d_scalars, int32_t n, int32
 int ozk_bases_create_host(const uint8_t* bases, int32_t n, int32_t type, int32_t task_id, void** handle);
 int ozk_var_msm_bases_host(void* handle, const uint8_t* scalars, int32_t n, uint8_t* out);
 int ozk_bases_destroy(void* handle);
+/* OZK_G1 / OZK_G2 for a live handle, 0 for a stale or released one (handles are validated by a magic
+ * word; ozk_bases_destroy keeps the 100-byte header allocated so that a late call fails with
+ * OZK_E_INVALID instead of touching freed memory). */
+int ozk_bases_type(void* handle);
 size_t ozk_var_msm_prepared_bytes(int32_t n, int32_t type);
 int ozk_var_msm_prepare_dev(const void* d_bases, int32_t n, int32_t type, void* d_prepared, size_t prepared_size,
                             void* stream);
@@ -176,6 +183,16 @@ int ozk_fixed_batch_msm_dev(int32_t outerc, int32_t window_size, int32_t n, cons
                             const void* d_scalars, int32_t bn_type, void* d_out,
                             void* d_workspace, size_t workspace_bytes, void* stream);
 int ozk_field_batch_mul_dev(const void* d_in, int32_t n, void* d_out, void* stream);
+/* Compact output (no counterpart in the reference, whose natives return 64-byte
+ * big-endian coordinates, algebra_msm_FixedBaseMSM.cu:783-787, i.e. 2x the bytes, and whose Java then
+ * re-marshals every key element for each proof, VariableBaseMSM.java:221-228): the same points, written
+ * as X|Y|Z 32-byte LITTLE-endian values — n x 96 B (G1) / n x 192 B (G2), exactly the wire-IN format of
+ * the variable-base natives, so a proving key goes from the setup to the prover as it is. */
+int ozk_fixed_batch_msm_compact_dev(int32_t outerc, int32_t window_size, int32_t n, const void* d_base,
+                                    const void* d_scalars, int32_t bn_type, void* d_out, void* d_workspace,
+                                    size_t workspace_bytes, void* stream);
+int ozk_fixed_batch_msm_compact_host(int32_t outerc, int32_t window_size, int32_t n, const uint8_t* base,
+                                     const uint8_t* scalars, int32_t bn_type, int32_t task_id, uint8_t* out);
 
 /* ---------------- radix-2 FFT over Fr -----------------------------------
  * replaces Java_algebra_fft_FFTAuxiliary_serialRadix2FFTNativeHelper
@@ -188,6 +205,12 @@ size_t ozk_fft_workspace_bytes(int32_t n);
 /* d_in: n x 32 B LE, d_out: n x 64 B LE (may not alias d_in). */
 int ozk_fft_dev(const void* d_in, int32_t n, const uint8_t* omega_host32, void* d_out,
                 void* d_workspace, size_t workspace_bytes, void* stream);
+/* Compact form: one flat buffer in, n x 32 B LE out (the reference's native walks a
+ * java.util.List<byte[]> with one JNI call per element and returns 64-byte values,
+ * algebra_fft_FFTAuxiliary.cu:228-255). */
+int ozk_fft_compact_host(const uint8_t* in, int32_t n, const uint8_t* omega, int32_t task_id, uint8_t* out);
+int ozk_fft_compact_dev(const void* d_in, int32_t n, const uint8_t* omega_host32, void* d_out,
+                        void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------- QAP witness map (the FFT path's caller) -------------
  * What R1CStoQAP.R1CStoQAPWitness (reductions/r1cs_to_qap/R1CStoQAP.java:163-230) does between the

@@ -293,12 +293,12 @@ static int fft_core(const u32* d_in, int n, const u32* tw, u32* d_out, int out_s
 }
 
 static int fft_dev(const void* d_in, int n, const uint8_t* omega_host, void* d_out, void* wsp, size_t wsb,
-                   hipStream_t st) {
+                   hipStream_t st, int out_stride = 16) {
   const FftLayout L = fft_layout(n, wsp, wsb);
   if (L.bytes > wsb) return fail(OZK_E_INVALID, "workspace too small: need %zu bytes, got %zu", L.bytes, wsb);
   OZK_HIP(hipMemcpyAsync(L.omega, omega_host, 32, hipMemcpyHostToDevice, st));
   fft_build_twiddles(L.omega, n, L.small, L.tw, st);
-  return fft_core((const u32*)d_in, n, L.tw, (u32*)d_out, 16, L.buf[0], L.buf[1], st);
+  return fft_core((const u32*)d_in, n, L.tw, (u32*)d_out, out_stride, L.buf[0], L.buf[1], st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -481,6 +481,14 @@ int ozk_fft_dev(const void* d_in, int32_t n, const uint8_t* omega_host32, void* 
   return fft_dev(d_in, n, omega_host32, d_out, d_workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+int ozk_fft_compact_dev(const void* d_in, int32_t n, const uint8_t* omega_host32, void* d_out, void* d_workspace,
+                        size_t workspace_bytes, void* stream) {
+  if (!d_in || !d_out || !omega_host32 || !d_workspace) return fail(OZK_E_INVALID, "null pointer argument");
+  if (n <= 0 || (n & (n - 1)) || n > (1 << 28))
+    return fail(OZK_E_INVALID, "FFT size %d is not a power of two in [1, 2^28]", n);
+  return fft_dev(d_in, n, omega_host32, d_out, d_workspace, workspace_bytes, (hipStream_t)stream, 8);
+}
+
 size_t ozk_qap_witness_workspace_bytes(int32_t m) {
   if (m <= 1 || (m & (m - 1))) return 0;
   return qap_layout(m, nullptr, 0).bytes;
@@ -533,13 +541,13 @@ int ozk_qap_witness_host(const uint8_t* A, const uint8_t* B, const uint8_t* C, i
   return OZK_OK;
 }
 
-int ozk_fft_host(const uint8_t* in, int32_t n, const uint8_t* omega, int32_t task_id, uint8_t* out) {
+static int fft_host(const uint8_t* in, int32_t n, const uint8_t* omega, int32_t task_id, uint8_t* out, int out_stride) {
   if (!in || !omega || !out) return fail(OZK_E_INVALID, "null pointer argument");
   if (n <= 0 || (n & (n - 1)) || n > (1 << 28))
     return fail(OZK_E_INVALID, "FFT size %d is not a power of two in [1, 2^28]", n);
   int rc = select_device(task_id);
   if (rc) return rc;
-  const size_t in_bytes = (size_t)n * 32, out_bytes = (size_t)n * 64;
+  const size_t in_bytes = (size_t)n * 32, out_bytes = (size_t)n * 4 * out_stride;
   const size_t wsb = ozk_fft_workspace_bytes(n);
   uint8_t* d = nullptr;
   hipStream_t st = nullptr;
@@ -554,7 +562,7 @@ int ozk_fft_host(const uint8_t* in, int32_t n, const uint8_t* omega, int32_t tas
   rc = OZK_OK;
   do {
     if ((e = hipMemcpyAsync(d, in, in_bytes, hipMemcpyHostToDevice, st)) != hipSuccess) break;
-    rc = fft_dev(d, n, omega, d_out, d_ws, wsb, st);
+    rc = fft_dev(d, n, omega, d_out, d_ws, wsb, st, out_stride);
     if (rc) break;
     if ((e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, st)) != hipSuccess) break;
     e = hipStreamSynchronize(st);
@@ -564,6 +572,13 @@ int ozk_fft_host(const uint8_t* in, int32_t n, const uint8_t* omega, int32_t tas
   if (rc) return rc;
   if (e != hipSuccess) return fail(OZK_E_NO_DEVICE, "HIP failure in fft_host: %s", hipGetErrorString(e));
   return OZK_OK;
+}
+
+int ozk_fft_host(const uint8_t* in, int32_t n, const uint8_t* omega, int32_t task_id, uint8_t* out) {
+  return fft_host(in, n, omega, task_id, out, 16);
+}
+int ozk_fft_compact_host(const uint8_t* in, int32_t n, const uint8_t* omega, int32_t task_id, uint8_t* out) {
+  return fft_host(in, n, omega, task_id, out, 8);
 }
 
 }  // extern "C"

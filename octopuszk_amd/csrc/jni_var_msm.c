@@ -61,13 +61,17 @@ JNIEXPORT jbyteArray JNICALL Java_algebra_msm_VariableBaseMSM_variableBaseSerial
   (void)cls;
   if (!handle) return ozk_throw(env, "null bases handle");
   if (batch_size <= 0) return ozk_throw(env, "batch_size must be positive");
+  /* the result's size follows the HANDLE's group; a mismatching `type` is a caller bug, not a truncation */
+  const int htype = ozk_bases_type((void*)(intptr_t)handle);
+  if (htype == 0) return ozk_throw(env, "stale or released bases handle");
+  if ((type == OZK_G1) != (htype == OZK_G1)) return ozk_throw(env, "type does not match the prepared bases");
   jbyte* s = ozk_borrow(env, scalars, 32LL * batch_size, "scalars");
   if (!s) return NULL;
-  uint8_t out[384];
+  uint8_t out[384] = {0};
   const int rc = ozk_var_msm_bases_host((void*)(intptr_t)handle, (const uint8_t*)s, batch_size, out);
   ozk_release(env, scalars, s);
   if (rc) return ozk_throw_last(env, "variableBaseSerialMSMPreparedNativeHelper", rc);
-  return ozk_result(env, out, type == OZK_G1 ? 192 : 384);
+  return ozk_result(env, out, htype == OZK_G1 ? 192 : 384);
 }
 
 JNIEXPORT void JNICALL Java_algebra_msm_VariableBaseMSM_releaseBasesNativeHelper(JNIEnv* env, jclass cls,

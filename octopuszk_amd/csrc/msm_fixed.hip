@@ -159,9 +159,12 @@ __device__ __forceinline__ void store_be_coord(const Fe2<B>& e, u32* p) {
 constexpr int FB_BATCH = 8;
 // lane t normalises results [t*FB_BATCH, ...): prefix products of Z, one inversion, back-substitution.
 // out element i is at out + i*out_stride_words (+ coordinate offsets).
+// compact = 1: X|Y|Z as 32-byte little-endian values (the wire-IN format of the variable-base natives,
+// VariableBaseMSM.java:221-228), so that keys go from the setup to the prover without being reformatted
+// (SURVEY.md §8f N4); compact = 0: the reference's 64-byte big-endian coordinates.
 template <class CV>
 __global__ void __launch_bounds__(256) k_fb_norm(const u32* __restrict__ jac, int n, u32* __restrict__ out,
-                                                 int out_stride_words) {
+                                                 int out_stride_words, int compact) {
   using IO = CurveIO<CV>;
   using EA = typename CV::EA;
   using ET = ElemTraits<EA>;
@@ -190,18 +193,31 @@ __global__ void __launch_bounds__(256) k_fb_norm(const u32* __restrict__ jac, in
       u32* o = out + (size_t)(lo + k) * out_stride_words;
       const auto Z = reduce_to<32>(p.Z);
       if (is_zero(Z)) {  // (0, 1, 0), BNG1.java:163-166
-        store_be_coord(EA(el_zero(p.X)), o);
-        store_be_coord(EA(el_one(p.X)), o + OW);
-        store_be_coord(EA(el_zero(p.X)), o + 2 * OW);
+        if (compact) {
+          ET::to_wire(EA(el_zero(p.X)), o);
+          ET::to_wire(EA(el_one(p.X)), o + ET::WORDS);
+          ET::to_wire(EA(el_zero(p.X)), o + 2 * ET::WORDS);
+        } else {
+          store_be_coord(EA(el_zero(p.X)), o);
+          store_be_coord(EA(el_one(p.X)), o + OW);
+          store_be_coord(EA(el_zero(p.X)), o + 2 * OW);
+        }
       } else {
         // 1/Z_k = invrun * prefix[k-1];  invrun <- invrun * Z_k
         EZ32 zi = invrun;
         if (k > 0) zi = EZ32(mul(invrun, prefix[k - 1]));
         invrun = EZ32(mul(invrun, Z));
         const auto zi2 = sqr(zi);
-        store_be_coord(EA(reduce_to<17>(mul(p.X, zi2))), o);
-        store_be_coord(EA(reduce_to<17>(mul(p.Y, mul(zi2, zi)))), o + OW);
-        store_be_coord(EA(el_one(p.X)), o + 2 * OW);
+        const EA ax = EA(reduce_to<17>(mul(p.X, zi2))), ay = EA(reduce_to<17>(mul(p.Y, mul(zi2, zi))));
+        if (compact) {
+          ET::to_wire(ax, o);
+          ET::to_wire(ay, o + ET::WORDS);
+          ET::to_wire(EA(el_one(p.X)), o + 2 * ET::WORDS);
+        } else {
+          store_be_coord(ax, o);
+          store_be_coord(ay, o + OW);
+          store_be_coord(EA(el_one(p.X)), o + 2 * OW);
+        }
       }
     }
   }
@@ -343,7 +359,7 @@ static int fb_check_args(int outerc, int ws, int n) {
 
 template <class CV>
 static int fixed_batch_dev(int outerc, int ws, int n, const void* d_base, const void* d_scalars, void* d_out,
-                           int out_stride_words, void* wsp, size_t wsb, hipStream_t st) {
+                           int out_stride_words, void* wsp, size_t wsb, hipStream_t st, int compact = 0) {
   using IO = CurveIO<CV>;
   const FbLayout L = fb_layout<CV>(outerc, ws, n, wsp, wsb);
   if (L.bytes > wsb) return fail(OZK_E_INVALID, "workspace too small: need %zu bytes, got %zu", L.bytes, wsb);
@@ -393,7 +409,7 @@ static int fixed_batch_dev(int outerc, int ws, int n, const void* d_base, const 
                        outerc, ws, L.jac);
   const int lanes = (n + FB_BATCH - 1) / FB_BATCH;
   hipLaunchKernelGGL((k_fb_norm<CV>), dim3((lanes + TB - 1) / TB), dim3(TB), 0, st, L.jac, n, (u32*)d_out,
-                     out_stride_words);
+                     out_stride_words, compact);
   OZK_HIP(hipGetLastError());
   return OZK_OK;
 }
@@ -432,16 +448,28 @@ int ozk_fixed_batch_msm_dev(int32_t outerc, int32_t ws, int32_t n, const void* d
                                 (hipStream_t)stream);
 }
 
-int ozk_fixed_batch_msm_host(int32_t outerc, int32_t ws, int32_t out_len, int32_t inner_len, int32_t n,
-                             int32_t scalar_size, const uint8_t* base, const uint8_t* scalars, int32_t bn_type,
-                             int32_t task_id, uint8_t* out) {
-  (void)out_len; (void)inner_len; (void)scalar_size;  // table shape is implied by outerc / windowSize
+int ozk_fixed_batch_msm_compact_dev(int32_t outerc, int32_t ws, int32_t n, const void* d_base, const void* d_scalars,
+                                    int32_t bn_type, void* d_out, void* d_workspace, size_t workspace_bytes,
+                                    void* stream) {
+  if (!d_base || !d_scalars || !d_out || !d_workspace) return fail(OZK_E_INVALID, "null pointer argument");
+  int rc = fb_check_args(outerc, ws, n);
+  if (rc) return rc;
+  if (bn_type == OZK_G1)
+    return fixed_batch_dev<G1Cfg>(outerc, ws, n, d_base, d_scalars, d_out, 24, d_workspace, workspace_bytes,
+                                  (hipStream_t)stream, 1);
+  return fixed_batch_dev<G2Cfg>(outerc, ws, n, d_base, d_scalars, d_out, 48, d_workspace, workspace_bytes,
+                                (hipStream_t)stream, 1);
+}
+
+static int fixed_batch_host(int32_t outerc, int32_t ws, int32_t n, const uint8_t* base, const uint8_t* scalars,
+                            int32_t bn_type, int32_t task_id, uint8_t* out, int compact) {
   if (!base || !scalars || !out) return fail(OZK_E_INVALID, "null pointer argument");
   int rc = fb_check_args(outerc, ws, n);
   if (rc) return rc;
   if ((rc = select_device(task_id))) return rc;
   const bool g1 = bn_type == OZK_G1;
-  const size_t base_bytes = g1 ? 96 : 192, sc_bytes = (size_t)n * 32, out_bytes = (size_t)n * (g1 ? 192 : 384);
+  const size_t base_bytes = g1 ? 96 : 192, sc_bytes = (size_t)n * 32;
+  const size_t out_bytes = (size_t)n * (g1 ? 192 : 384) / (compact ? 2 : 1);
   const size_t wsb = ozk_fixed_batch_msm_workspace_bytes(outerc, ws, n, bn_type);
   DevBuf d;
   OZK_HIP(hipStreamCreateWithFlags(&d.st, hipStreamNonBlocking));
@@ -449,11 +477,24 @@ int ozk_fixed_batch_msm_host(int32_t outerc, int32_t ws, int32_t out_len, int32_
   OZK_HIP(hipMalloc((void**)&d.p, a2 + wsb + 256));
   OZK_HIP(hipMemcpyAsync(d.p, base, base_bytes, hipMemcpyHostToDevice, d.st));
   OZK_HIP(hipMemcpyAsync(d.p + a0, scalars, sc_bytes, hipMemcpyHostToDevice, d.st));
-  rc = ozk_fixed_batch_msm_dev(outerc, ws, n, d.p, d.p + a0, bn_type, d.p + a1, d.p + a2, wsb, d.st);
+  rc = compact ? ozk_fixed_batch_msm_compact_dev(outerc, ws, n, d.p, d.p + a0, bn_type, d.p + a1, d.p + a2, wsb, d.st)
+               : ozk_fixed_batch_msm_dev(outerc, ws, n, d.p, d.p + a0, bn_type, d.p + a1, d.p + a2, wsb, d.st);
   if (rc) return rc;
   OZK_HIP(hipMemcpyAsync(out, d.p + a1, out_bytes, hipMemcpyDeviceToHost, d.st));
   OZK_HIP(hipStreamSynchronize(d.st));
   return OZK_OK;
+}
+
+int ozk_fixed_batch_msm_host(int32_t outerc, int32_t ws, int32_t out_len, int32_t inner_len, int32_t n,
+                             int32_t scalar_size, const uint8_t* base, const uint8_t* scalars, int32_t bn_type,
+                             int32_t task_id, uint8_t* out) {
+  (void)out_len; (void)inner_len; (void)scalar_size;  // table shape is implied by outerc / windowSize
+  return fixed_batch_host(outerc, ws, n, base, scalars, bn_type, task_id, out, 0);
+}
+
+int ozk_fixed_batch_msm_compact_host(int32_t outerc, int32_t ws, int32_t n, const uint8_t* base,
+                                     const uint8_t* scalars, int32_t bn_type, int32_t task_id, uint8_t* out) {
+  return fixed_batch_host(outerc, ws, n, base, scalars, bn_type, task_id, out, 1);
 }
 
 int ozk_fixed_double_batch_msm_host(int32_t outerc1, int32_t ws1, int32_t outerc2, int32_t ws2, int32_t out_len1,

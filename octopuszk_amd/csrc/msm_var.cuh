@@ -1208,29 +1208,18 @@ __device__ void write_normalised(const Jac<CV>& r, u32* out) {
 
 // A_w holds S_w (one element per window after the last wsum level, with 2^g * 0 * R = 0).
 //
-// The Horner chain runs on ONE lane for ~1.5 ms.  When another MSM's bucket accumulation shares
-// its SIMD, either the chain starves (no priority) or — with s_setprio — the co-resident
-// accumulation waves crawl and that whole kernel waits for them (measured: 1.38 -> 1.65 ms).
-// EXCLUSIVE = true lets the kernel take a compute unit for itself: four waves, one per SIMD, each
-// declaring all 512 VGPRs; wave 0 works, the other three sleep until it is done.  The accumulation
-// kernel then loses 1 CU of 256 instead of 20 % of its time — experimental, see msm_var.hip.
-template <class CV, bool EXCLUSIVE>
-__global__ void __launch_bounds__(EXCLUSIVE ? 256 : 64) k_finalize(const u32* __restrict__ A_w, const u32* __restrict__ R_w, int m,
-                                                  int g, int W, int c, int sd, u32* __restrict__ out) {
+// The Horner chain over the windows is serial: one wave (one lane, or a lane pair for G2), issue
+// priority raised.  (Round 1 also carried a variant that declared a whole CU's register files so that no
+// accumulation wave shared its SIMDs.  A process abort seen with it was the sort's missing barrier wait,
+// see block_sync() in curve.cuh, not this kernel: with that fixed the variant passed the whole GPU suite,
+// and measured 519.0 against 516.1 Mscalar-mul/s pipelined — inside the run-to-run noise — so it was
+// removed; profiles/r02_finalize_exclusive_ab.txt.)
+template <class CV>
+__global__ void __launch_bounds__(64) k_finalize(const u32* __restrict__ A_w, const u32* __restrict__ R_w, int m,
+                                                 int g, int W, int c, int sd, u32* __restrict__ out) {
   using IO = CurveIO<CV>;
-  __shared__ volatile int done;
   __shared__ u32 sw[64 * IO::JAC_WORDS];  // S_w of up to 64 windows at a time
-  if constexpr (EXCLUSIVE) {
-    // 256 VGPRs + 256 AGPRs = the SIMD's whole register file
-    asm volatile("v_mov_b32 v255, 0\n\tv_accvgpr_write_b32 a255, 0" ::: "v255", "a255");
-  }
   if (blockIdx.x != 0) return;
-  if (threadIdx.x == 0) done = 0;
-  block_sync();
-  if (threadIdx.x >= 64) {  // placeholder waves: hold the SIMD's registers, issue (almost) nothing
-    while (!done) __builtin_amdgcn_s_sleep(64);
-    return;
-  }
   __builtin_amdgcn_s_setprio(3);
   // The last window-sum level left m (<= a few) elements (A_j, R_j) per window:
   //     S_w = sum_j A_j + 2^g * sum_j j * R_j     (+ sum_j R_j with signed digits: bucket b weighs b + 1)
@@ -1274,10 +1263,7 @@ __global__ void __launch_bounds__(EXCLUSIVE ? 256 : 64) k_finalize(const u32* __
     }
     __builtin_amdgcn_wave_barrier();
   }
-  if (l == 0) {
-    write_normalised<CV>(from_pair(r), out);
-    done = 1;
-  }
+  if (l == 0) write_normalised<CV>(from_pair(r), out);
 }
 
 // sum of k points given in wire-out format (affine or (0,1,0)); used for the multi-GPU reduce

@@ -95,12 +95,24 @@ int ozk_bases_create_host(const uint8_t* bases, int32_t n, int32_t type, int32_t
 int ozk_var_msm_bases_host(void* handle, const uint8_t* scalars, int32_t n, uint8_t* out) {
   if (!handle || !scalars || !out) return fail(OZK_E_INVALID, "null pointer argument");
   BasesHandle* h = (BasesHandle*)handle;
+  if (h->magic != BASES_MAGIC) return fail(OZK_E_INVALID, "not a live bases handle (stale or already released)");
   if (n != h->n) return fail(OZK_E_INVALID, "batch_size %d does not match the prepared bases (%d)", n, h->n);
   return h->type == OZK_G1 ? bases_msm<G1Cfg>(h, scalars, out) : bases_msm<G2Cfg>(h, scalars, out);
+}
+int ozk_bases_type(void* handle) {
+  BasesHandle* h = (BasesHandle*)handle;
+  if (!h || h->magic != BASES_MAGIC) return 0;
+  return h->type;
 }
 int ozk_bases_destroy(void* handle) {
   if (!handle) return OZK_OK;
   BasesHandle* h = (BasesHandle*)handle;
+  if (h->magic != BASES_MAGIC) return fail(OZK_E_INVALID, "not a live bases handle (stale or already released)");
+  // wait for an MSM in flight on this handle, then mark it dead before anything is freed (the memory of
+  // the handle itself is kept: a late caller holding the stale pointer gets OZK_E_INVALID, not a crash)
+  pthread_mutex_lock(&h->mu);
+  h->magic = 0;
+  pthread_mutex_unlock(&h->mu);
   hipSetDevice(h->device);
   hipStreamSynchronize(h->st);
   hipFree(h->d_prepared);
@@ -108,8 +120,13 @@ int ozk_bases_destroy(void* handle) {
   hipFree(h->d_out);
   hipFree(h->d_ws);
   hipStreamDestroy(h->st);
-  pthread_mutex_destroy(&h->mu);
-  free(h);
+  h->d_prepared = h->d_scalars = h->d_out = h->d_ws = nullptr;
+  h->st = nullptr;
+  return OZK_OK;
+}
+
+int ozk_tuning_reload(void) {
+  env_reload();
   return OZK_OK;
 }
 

@@ -276,6 +276,11 @@ int var_msm_sort(const void* d_bases, const void* d_scalars, int n, void* sorted
   const int nbins = p.W * L.NH;
   const u32 sign_bit = p.sd ? 0x80u : 0u;
   const u32 big_thresh = (u32)(n / 64) > SORT_BIG ? (u32)(n / 64) : SORT_BIG;
+  // at most cap / (big_thresh + 1) bins can exceed the threshold; the device work list holds SORTBIG_MAXBINS
+  // (always enough for the library's own plans: 64 W <= 1024 for W <= 16; a forced tiny window at a large n is not)
+  if (L.cap / ((size_t)big_thresh + 1) > (size_t)SORTBIG_MAXBINS)
+    return fail(OZK_E_INVALID, "window plan c=%d (W=%d) at n=%d can produce more than %d oversized sort bins",
+                p.c, p.W, p.n_in, SORTBIG_MAXBINS);
   hipLaunchKernelGGL(k_sort2, dim3(nbins), dim3(SORT_BLOCK), 0, st, L.coarse, L.P1, L.total, p.cb, L.lo_bits, L.NH,
                      sign_bit, L.nblk, nbins, big_thresh, L.hist, L.sidx, L.sbid);
   // Ordering hint for pipelined MSMs (see ozk_var_msm_tail_ordered_dev): everything up to here may
@@ -425,17 +430,9 @@ int var_msm_tail(int n, void* tail, size_t tail_bytes, void* d_out, hipStream_t 
     k ^= 1;
   }
   if (order_ev && !order_early) OZK_HIP(hipEventRecord(order_ev, st));  // the multi-wave levels are done
-  // One wave (Horner is serial).  EXPERIMENTAL (off): with OZK_FINALIZE_EXCLUSIVE=1 the kernel runs four
-  // waves that declare the whole register file of a CU so that no bucket-accumulation wave shares its
-  // SIMDs: +9 % pipelined throughput when measured, but the process aborted reproducibly when ~60 HIP
-  // streams had been created and destroyed before it (suspected: mid-wave preemption of 512-register
-  // waves under queue oversubscription), so it is not the default.
-  if (env_int("OZK_FINALIZE_EXCLUSIVE", 0))
-    hipLaunchKernelGGL((k_finalize<CT, true>), dim3(1), dim3(256), 0, st, L.wA[k], L.wR[k], m_in, g, p.W, p.c,
-                       p.sd, (u32*)d_out);
-  else
-    hipLaunchKernelGGL((k_finalize<CT, false>), dim3(1), dim3(64), 0, st, L.wA[k], L.wR[k], m_in, g, p.W, p.c,
-                       p.sd, (u32*)d_out);
+  // one wave: Horner over the windows is serial
+  hipLaunchKernelGGL((k_finalize<CT>), dim3(1), dim3(64), 0, st, L.wA[k], L.wR[k], m_in, g, p.W, p.c, p.sd,
+                     (u32*)d_out);
   OZK_HIP(hipGetLastError());
   return OZK_OK;
 }
@@ -531,7 +528,9 @@ int var_msm_prepare(const void* d_bases, int n, void* d_prepared, size_t bytes, 
 }
 
 // Host-side handle: prepared bases + everything an MSM over them needs, allocated once.
+constexpr uint32_t BASES_MAGIC = 0x4f5a4b42u;  // "OZKB": set by create, cleared by destroy
 struct BasesHandle {
+  uint32_t magic;
   int device, n, type;
   hipStream_t st;
   uint8_t *d_prepared, *d_scalars, *d_out, *d_ws;
@@ -548,7 +547,7 @@ int bases_create(const uint8_t* bases, int n, int type, int task_id, BasesHandle
   if (!h) return fail(OZK_E_NOMEM, "out of host memory");
   hipGetDevice(&h->device);
   h->n = n;
-  h->type = type;
+  h->type = type == OZK_G1 ? OZK_G1 : OZK_G2;
   pthread_mutex_init(&h->mu, nullptr);
   const size_t wire = (size_t)n * IO::WIRE_JAC_WORDS * 4, pb = prepared_bytes<CV>(n);
   h->ws_bytes = var_msm_ws_bytes<CV>(n);
@@ -574,6 +573,7 @@ int bases_create(const uint8_t* bases, int n, int type, int task_id, BasesHandle
     if (rc) return rc;
     return fail(OZK_E_NOMEM, "HIP failure while preparing bases: %s", hipGetErrorString(e));
   }
+  h->magic = BASES_MAGIC;
   *out = h;
   return OZK_OK;
 }
@@ -582,6 +582,10 @@ template <class CV>
 int bases_msm(BasesHandle* h, const uint8_t* scalars, uint8_t* out) {
   const size_t out_bytes = (size_t)CurveIO<CV>::WIRE_JAC_WORDS * 8;
   pthread_mutex_lock(&h->mu);
+  if (h->magic != BASES_MAGIC) {  // released while this call waited for the lock
+    pthread_mutex_unlock(&h->mu);
+    return fail(OZK_E_INVALID, "bases handle was released");
+  }
   int rc = OZK_OK;
   hipError_t e = hipSetDevice(h->device);
   do {

@@ -3,6 +3,8 @@
 // library-owned workspace.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <pthread.h>
+#include <stdlib.h>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -65,9 +67,48 @@ inline int ilog2(uint32_t v) {
   while (v >>= 1) r++;
   return r;
 }
+// Tuning switches (OZK_* environment variables) are read ONCE per process and cached: an MSM asks for
+// its plan several times (workspace-size query, head, tail), and a variable changing in between would
+// desynchronise the layouts.  ozk_tuning_reload() (tests, tuning scripts) drops the cache.
+struct EnvCache {
+  pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+  int n = 0;
+  char names[64][40];
+  int vals[64];
+  bool has[64];
+};
+inline EnvCache& env_cache() {
+  static EnvCache c;
+  return c;
+}
 inline int env_int(const char* name, int dflt) {
-  const char* s = getenv(name);
-  return (s && *s) ? atoi(s) : dflt;
+  EnvCache& c = env_cache();
+  pthread_mutex_lock(&c.mu);
+  int k = 0;
+  for (; k < c.n; k++)
+    if (strcmp(c.names[k], name) == 0) break;
+  if (k == c.n && c.n < 64 && strlen(name) < 40) {
+    const char* s = getenv(name);
+    strcpy(c.names[k], name);
+    c.has[k] = s && *s;
+    c.vals[k] = c.has[k] ? atoi(s) : 0;
+    c.n++;
+  }
+  int r = dflt;
+  if (k < c.n) {
+    if (c.has[k]) r = c.vals[k];
+  } else {  // table full: uncached
+    const char* s = getenv(name);
+    if (s && *s) r = atoi(s);
+  }
+  pthread_mutex_unlock(&c.mu);
+  return r;
+}
+inline void env_reload() {
+  EnvCache& c = env_cache();
+  pthread_mutex_lock(&c.mu);
+  c.n = 0;
+  pthread_mutex_unlock(&c.mu);
 }
 
 }  // namespace ozk

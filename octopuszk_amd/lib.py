@@ -51,6 +51,12 @@ _SIGS = {
     "ozk_fixed_batch_msm_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "ozk_fixed_batch_msm_dev": (ctypes.c_int, [i32, i32, i32, vp, vp, i32, vp, vp, sz, vp]),
     "ozk_field_batch_mul_dev": (ctypes.c_int, [vp, i32, vp, vp]),
+    "ozk_fixed_batch_msm_compact_dev": (ctypes.c_int, [i32, i32, i32, vp, vp, i32, vp, vp, sz, vp]),
+    "ozk_fixed_batch_msm_compact_host": (ctypes.c_int, [i32, i32, i32, vp, vp, i32, i32, vp]),
+    "ozk_fft_compact_host": (ctypes.c_int, [vp, i32, vp, i32, vp]),
+    "ozk_fft_compact_dev": (ctypes.c_int, [vp, i32, vp, vp, vp, sz, vp]),
+    "ozk_tuning_reload": (ctypes.c_int, []),
+    "ozk_bases_type": (ctypes.c_int, [vp]),
     "ozk_fft_host": (ctypes.c_int, [vp, i32, vp, i32, vp]),
     "ozk_fft_workspace_bytes": (sz, [i32]),
     "ozk_fft_dev": (ctypes.c_int, [vp, i32, vp, vp, vp, sz, vp]),

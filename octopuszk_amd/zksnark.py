@@ -1,0 +1,556 @@
+"""Host-side mirror of the reference's SERIAL Groth16 setup and prover for BN254a — the callers of the
+MSM / FFT hot path (BASELINE.json configs[4]) — with every group / transform
+operation on the GPU through the C ABI of libozk_hip.so and the keys resident in HBM between them.
+
+    serial_construct        profiler/generation/R1CSConstruction.java:28-110   (synthetic R1CS + witness)
+    r1cs_to_qap_relation    reductions/r1cs_to_qap/R1CStoQAP.java:37-98        (QAP instance at t; host)
+    SerialSetup.generate    zk_proof_systems/zkSNARK/SerialSetup.java:32-192   (4 x batchMSM + doubleBatchMSM)
+    SerialProver.prove      zk_proof_systems/zkSNARK/SerialProver.java:26-119  (witness map, 4 x serialMSM,
+                                                                                2 x doubleMSM, assembly)
+
+What runs where.  The reference keeps field elements as BigInteger objects on the JVM heap and crosses
+the JNI for each MSM / batch; here the host side is Python ints (the image has no JDK) for exactly the
+parts the Java does on the CPU (R1CS construction, Lagrange coefficients, the sparse accumulation of
+A_i(t), B_i(t), C_i(t), constraint evaluation), and device buffers for everything else:
+
+  * setup: the five fixed-base batches write the proving key straight into the wire-in format of the
+    variable-base MSM (ozk_fixed_batch_msm_compact_dev), so the key never leaves HBM;
+  * prove: constraint evaluations are uploaded once, ozk_qap_witness_dev leaves coefficientsH in HBM, the
+    MSMs run over bases prepared once per key (ozk_var_msm_prepare_dev) — G1 through a two-stage pipeline on
+    two streams, G2 on a third — and the proof is assembled on the device (ozk_points_sum_dev and one
+    5-term MSM) from the MSM results.
+
+Proof elements are returned in the wire-out format of the variable-base natives (affine-normalised,
+64-byte little-endian coordinates).  There is no CPU fallback: without the HIP library nothing here works.
+"""
+import ctypes
+import time
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+from .fft import FR, FR_MULT_GEN, root_of_unity
+from .fixed_base_msm import G1_WINDOW_TABLE, G2_WINDOW_TABLE, get_window_size
+
+SEED = 10  # configuration/Configuration.java:52
+G1_ONE = (1, 2, 1)  # BN254aG1Parameters.java:23-24
+G2_ONE = (  # BN254aG2Parameters.java:25-32
+    (10857046999023057135944570762232829481370756359578518086990519993285655852781,
+     11559732032986387107991004021392285783925812861821192530917403151452391805634),
+    (8495653923123431417604973247489272438418190587263600148770280649306958101930,
+     4082367875863433681332203403145435568316851327593401208105741076214120093531),
+    (1, 0))
+
+
+# ---------------------------------------------------------------------------- small helpers
+def _java_random_next_long(seed: int) -> int:
+    """new java.util.Random(seed).nextLong() (JDK API specification: 48-bit LCG, two signed 32-bit draws)."""
+    mult, mask = 0x5DEECE66D, (1 << 48) - 1
+    st = (seed ^ mult) & mask
+    out = []
+    for _ in range(2):
+        st = (st * mult + 0xB) & mask
+        v = st >> 16
+        out.append(v - (1 << 32) if v >= 1 << 31 else v)
+    v = ((out[0] << 32) + out[1]) & ((1 << 64) - 1)
+    return v - (1 << 64) if v >= 1 << 63 else v
+
+
+def fr_random(seed: int = SEED) -> int:
+    """Fp.random (algebra/fields/Fp.java:72-80): new Fp(new Random(seed).nextLong()) — reduced mod r by the
+    constructor, so every draw with the same seed is the same element."""
+    return _java_random_next_long(seed) % FR
+
+
+def lowest_power_of_two(n: int) -> int:
+    """common/MathUtils.java:20-41."""
+    r = 1
+    while r < n:
+        r <<= 1
+    return r
+
+
+def _le32(values) -> bytes:
+    return b"".join(int(v).to_bytes(32, "little") for v in values)
+
+
+def _dev_bytes(b: bytes) -> torch.Tensor:
+    return torch.from_numpy(np.frombuffer(b, dtype=np.uint8).copy()).cuda()
+
+
+def _ptr(t):
+    return int(t.data_ptr())
+
+
+def _stream():
+    return int(torch.cuda.current_stream().cuda_stream)
+
+
+def g1_wire(P) -> bytes:
+    return _le32(P)
+
+
+def g2_wire(P) -> bytes:
+    return _le32(P[i][j] for i in range(3) for j in range(2))
+
+
+def wire_out_to_in(out: torch.Tensor, type_: int) -> torch.Tensor:
+    """One point in the natives' return layout (64-byte LE coordinates, upper half zero) -> the 32-byte
+    coordinates they take as input (VariableBaseMSM.java:221-228 vs :239-258)."""
+    k = 3 if type_ == 1 else 6
+    return out.view(k, 64)[:, :32].reshape(-1).contiguous()
+
+
+# ---------------------------------------------------------------------------- R1CS (CSR arrays)
+class LinearCombinations:
+    """The A (or B, or C) side of all constraints: row i = terms ptr[i] .. ptr[i+1] of (index, value).
+    value is None when every coefficient is `one` (the synthetic circuits)."""
+
+    def __init__(self, ptr, index, value=None):
+        self.ptr = np.asarray(ptr, dtype=np.int64)
+        self.index = np.asarray(index, dtype=np.int64)
+        self.value = value  # None, or a numpy object array of Python ints
+
+    @property
+    def rows(self):
+        return len(self.ptr) - 1
+
+    def row_of_term(self):
+        return np.repeat(np.arange(self.rows, dtype=np.int64), np.diff(self.ptr))
+
+    def evaluate(self, full_obj):
+        """LinearCombination.evaluate (relations/objects/LinearCombination.java:39-50) for every row: a term
+        with index 0 contributes `one` whatever its coefficient."""
+        vals = full_obj[self.index]
+        if self.value is not None:
+            vals = vals * self.value
+        vals[self.index == 0] = 1
+        out = np.zeros(self.rows, dtype=object)
+        nz = np.diff(self.ptr) > 0
+        if nz.any():
+            red = np.add.reduceat(vals, self.ptr[:-1][nz])
+            out[nz] = red
+        return out % FR
+
+
+class R1CSRelation:
+    def __init__(self, A, B, C, num_inputs, num_auxiliary):
+        self.A, self.B, self.C = A, B, C
+        self.num_inputs, self.num_auxiliary = num_inputs, num_auxiliary
+        self.num_variables = num_inputs + num_auxiliary
+        self.num_constraints = A.rows
+
+
+def serial_construct(num_constraints: int, num_inputs: int, seed: int = SEED):
+    """R1CSConstruction.serialConstruct (R1CSConstruction.java:28-110): the alternating a + b = c / a * b = c
+    chain, closed by one constraint (sum x_i)^2 = x_last.  Returns (r1cs, primary, auxiliary) with the
+    assignments as lists of ints."""
+    assert num_inputs <= num_constraints + 1
+    nc = num_constraints
+    num_auxiliary = 3 + nc - num_inputs
+    nv = num_inputs + num_auxiliary
+    a = fr_random(seed)
+    b = fr_random(seed)
+    full = [1, a, b]
+    for i in range(nc - 1):
+        tmp = (a * b) % FR if i % 2 else (a + b) % FR
+        a, b = b, tmp
+        full.append(tmp)
+    res = sum(full[1:nv - 1]) % FR
+    full.append(res * res % FR)
+    i = np.arange(nc - 1, dtype=np.int64)
+    even = (i % 2) == 0
+    tail = np.arange(1, nv - 1, dtype=np.int64)
+    # A: [i+1, i+2] on even rows (a + b), [i+1] on odd rows (a * b); last row: all of 1 .. nv-2
+    a_cnt = np.where(even, 2, 1)
+    a_ptr = np.concatenate(([0], np.cumsum(a_cnt)))
+    a_idx = np.empty(int(a_ptr[-1]), dtype=np.int64)
+    a_idx[a_ptr[:-1]] = i + 1
+    a_idx[a_ptr[:-1][even] + 1] = i[even] + 2
+    A = LinearCombinations(np.concatenate((a_ptr, [a_ptr[-1] + len(tail)])), np.concatenate((a_idx, tail)))
+    # B: [0] on even rows, [i+2] on odd rows; last row as A
+    b_idx = np.where(even, 0, i + 2)
+    B = LinearCombinations(np.concatenate((np.arange(nc, dtype=np.int64), [nc - 1 + len(tail)])),
+                           np.concatenate((b_idx, tail)))
+    # C: [i+3]; last row [nv-1]
+    C = LinearCombinations(np.arange(nc + 1, dtype=np.int64), np.concatenate((i + 3, [nv - 1])))
+    r1cs = R1CSRelation(A, B, C, num_inputs, num_auxiliary)
+    assert len(full) == nv
+    return r1cs, full[:num_inputs], full[num_inputs:]
+
+
+def constraint_evaluations(r1cs: R1CSRelation, full):
+    """The three vectors R1CStoQAP.R1CStoQAPWitness fills before its transforms (R1CStoQAP.java:143-160,
+    195-199): evaluations of A, B, C on the domain, with the extra constraints input_i * 0 = 0."""
+    nc, ni = r1cs.num_constraints, r1cs.num_inputs
+    m = lowest_power_of_two(nc + ni)
+    z = np.array(full, dtype=object)
+    ev = []
+    for k, lc in enumerate((r1cs.A, r1cs.B, r1cs.C)):
+        v = np.zeros(m, dtype=object)
+        v[:nc] = lc.evaluate(z)
+        if k == 0:
+            v[nc:nc + ni] = z[:ni]
+        ev.append(v)
+    return ev, m
+
+
+def is_satisfied(r1cs: R1CSRelation, primary, auxiliary) -> bool:
+    ev, _ = constraint_evaluations(r1cs, list(primary) + list(auxiliary))
+    nc = r1cs.num_constraints
+    return bool(np.all((ev[0][:nc] * ev[1][:nc] - ev[2][:nc]) % FR == 0))
+
+
+# ---------------------------------------------------------------------------- QAP instance at t (host)
+def _batch_inverse(xs):
+    """Montgomery's trick over Python ints (the Java calls BigInteger.modInverse once per element)."""
+    n = len(xs)
+    pref = [1] * (n + 1)
+    acc = 1
+    for i, x in enumerate(xs):
+        acc = acc * x % FR
+        pref[i + 1] = acc
+    inv = pow(acc, -1, FR)
+    out = [0] * n
+    for i in range(n - 1, -1, -1):
+        out[i] = inv * pref[i] % FR
+        inv = inv * xs[i] % FR
+    return out
+
+
+def lagrange_coefficients(t: int, m: int):
+    """FFTAuxiliary.serialRadix2LagrangeCoefficients (FFTAuxiliary.java:250-302)."""
+    if m == 1:
+        return [1]
+    omega = root_of_unity(m)
+    if pow(t, m, FR) == 1:   # t is a domain element: one coefficient is 1
+        out, w = [0] * m, 1
+        for i in range(m):
+            if w == t:
+                out[i] = 1
+                return out
+            w = w * omega % FR
+    Z = (pow(t, m, FR) - 1) % FR
+    l = Z * pow(m, -1, FR) % FR
+    ls, ds, r = [], [], 1
+    for _ in range(m):
+        ls.append(l)
+        ds.append((t - r) % FR)
+        l = l * omega % FR
+        r = r * omega % FR
+    inv = _batch_inverse(ds)
+    return [a * b % FR for a, b in zip(ls, inv)]
+
+
+class QAPRelation:
+    pass
+
+
+def r1cs_to_qap_relation(r1cs: R1CSRelation, t: int) -> QAPRelation:
+    """R1CStoQAP.R1CStoQAPRelation (R1CStoQAP.java:37-98)."""
+    nc, ni, nv = r1cs.num_constraints, r1cs.num_inputs, r1cs.num_variables
+    m = lowest_power_of_two(nc + ni)
+    lag = np.array(lagrange_coefficients(t, m), dtype=object)
+    q = QAPRelation()
+    out = []
+    for k, lc in enumerate((r1cs.A, r1cs.B, r1cs.C)):
+        acc = np.zeros(nv, dtype=object)
+        if k == 0:
+            acc[:ni] = lag[nc:nc + ni]
+        contrib = lag[lc.row_of_term()]
+        if lc.value is not None:
+            contrib = contrib * lc.value
+        np.add.at(acc, lc.index, contrib)
+        out.append([int(x) for x in (acc % FR)])
+    q.At, q.Bt, q.Ct = out
+    ht, ti = [], 1
+    for _ in range(m + 1):
+        ht.append(ti)
+        ti = ti * t % FR
+    q.Ht = ht
+    q.Zt = (pow(t, m, FR) - 1) % FR   # SerialFFT.computeZ (SerialFFT.java:140-142)
+    q.t, q.num_inputs, q.num_variables, q.degree = t, ni, nv, m
+    return q
+
+
+# ---------------------------------------------------------------------------- fixed-base batches on the device
+def _num_windows(scalar_size, window_size):
+    return scalar_size // window_size if scalar_size % window_size == 0 else scalar_size // window_size + 1
+
+
+def batch_msm_dev(scalar_size: int, window_size: int, base_wire: bytes, scalars, type_: int) -> torch.Tensor:
+    """FixedBaseMSM.batchMSM (FixedBaseMSM.java:186-315) with the result left in HBM in the variable-base
+    wire-in format: uint8 tensor n x 96 (G1) / n x 192 (G2)."""
+    L = _lib.load()
+    n = len(scalars)
+    outerc = (scalar_size + window_size - 1) // window_size   # FixedBaseMSM.java:212
+    if outerc * window_size < 254:
+        raise _lib.OzkError("window plan covers %d bits of a 254-bit scalar" % (outerc * window_size))
+    d_base = _dev_bytes(base_wire)
+    d_sc = _dev_bytes(_le32(scalars))
+    out = torch.empty(n * (96 if type_ == 1 else 192), dtype=torch.uint8, device="cuda")
+    wsb = int(L.ozk_fixed_batch_msm_workspace_bytes(outerc, window_size, n, type_))
+    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    _lib.check(L.ozk_fixed_batch_msm_compact_dev(outerc, window_size, n, _ptr(d_base), _ptr(d_sc), type_, _ptr(out),
+                                                 _ptr(ws), wsb, _stream()))
+    torch.cuda.current_stream().synchronize()   # ws / d_sc die here
+    return out
+
+
+def _bit_size(wire: bytes) -> int:
+    """BNG1.bitSize / BNG2.bitSize (BNG1.java:174-176): the longest coordinate."""
+    return max(int.from_bytes(wire[k:k + 32], "little").bit_length() for k in range(0, len(wire), 32))
+
+
+class ProvingKey:
+    """zk_proof_systems/zkSNARK/objects/ProvingKey.java, every group element resident in HBM in the
+    variable-base wire-in format."""
+
+
+class CRS:
+    pass
+
+
+def serial_setup_generate(r1cs: R1CSRelation, seed: int = SEED, log=None) -> CRS:
+    """SerialSetup.generate (SerialSetup.java:32-192) without the pairing of the verification key."""
+    tm = {}
+    t0 = time.perf_counter()
+    t = alpha = beta = gamma = delta = fr_random(seed)          # :40-44
+    inv_gamma, inv_delta = pow(gamma, -1, FR), pow(delta, -1, FR)
+    qap = r1cs_to_qap_relation(r1cs, t)                         # :50
+    tm["qap_relation_host_s"] = time.perf_counter() - t0
+    ni, nv = qap.num_inputs, qap.num_variables
+    abc = [(beta * a + alpha * b + c) % FR for a, b, c in zip(qap.At, qap.Bt, qap.Ct)]
+    gamma_abc = [x * inv_gamma % FR for x in abc[:ni]]          # :61-66
+    delta_abc = [x * inv_delta % FR for x in abc[ni:]]          # :69-74
+    non_zero_at = sum(1 for x in qap.At if x)                   # :76-88
+    non_zero_bt = sum(1 for x in qap.Bt if x)
+    # :91-112 generators = one * random, window sizes from the per-curve tables
+    rnd = fr_random(seed)
+    gen_g1 = bytes(batch_msm_dev(254, 16, g1_wire(G1_ONE), [rnd], 1).cpu().numpy())
+    gen_g2 = bytes(batch_msm_dev(254, 16, g2_wire(G2_ONE), [rnd], 2).cpu().numpy())
+    scalar_size_g1, scalar_size_g2 = _bit_size(gen_g1), _bit_size(gen_g2)
+    window_g1 = get_window_size(non_zero_at + non_zero_bt + nv, G1_WINDOW_TABLE)
+    window_g2 = get_window_size(non_zero_bt, G2_WINDOW_TABLE)
+    t1 = time.perf_counter()
+
+    def b1(scalars):
+        return batch_msm_dev(scalar_size_g1, window_g1, gen_g1, scalars, 1)
+
+    def b2(scalars):
+        return batch_msm_dev(scalar_size_g2, window_g2, gen_g2, scalars, 2)
+
+    pk = ProvingKey()
+    k1 = b1([alpha, beta, delta])                               # :117-121
+    pk.alpha_g1, pk.beta_g1, pk.delta_g1 = k1[:96], k1[96:192], k1[192:288]
+    k2 = b2([beta, delta, gamma])
+    pk.beta_g2, pk.delta_g2, gamma_g2 = k2[:192], k2[192:384], k2[384:576]
+    pk.delta_abc_g1 = b1(delta_abc)                             # :123-126
+    pk.query_a = b1(qap.At)                                     # :128-131
+    pk.query_b_g1 = b1(qap.Bt)                                  # :133-144 doubleBatchMSM: G1 and G2 over Bt
+    pk.query_b_g2 = b2(qap.Bt)
+    inv_delta_zt = qap.Zt * inv_delta % FR                      # :146-151
+    ht_scalars = [h * inv_delta_zt % FR for h in qap.Ht]
+    pk.query_h = b1(ht_scalars)
+    pk.r1cs = r1cs
+    crs = CRS()
+    crs.proving_key = pk
+    crs.gamma_g2 = gamma_g2                                     # :160-164
+    crs.gamma_abc_g1 = b1(gamma_abc)
+    tm["fixed_base_gpu_s"] = time.perf_counter() - t1
+    # kept for checks in the exponent (tests): the scalars behind every key element
+    crs.qap = qap
+    crs.secrets = dict(t=t, alpha=alpha, beta=beta, gamma=gamma, delta=delta, generator=rnd)
+    crs.scalars = dict(delta_abc=delta_abc, gamma_abc=gamma_abc, ht=ht_scalars)
+    crs.gen_g1, crs.gen_g2 = gen_g1, gen_g2
+    crs.window_g1, crs.window_g2 = window_g1, window_g2
+    crs.scalar_size_g1, crs.scalar_size_g2 = scalar_size_g1, scalar_size_g2
+    crs.timing = tm
+    if log:
+        log("setup: QAP instance (host) %.2f s, fixed-base batches (GPU, incl. marshalling) %.2f s"
+            % (tm["qap_relation_host_s"], tm["fixed_base_gpu_s"]))
+    return crs
+
+
+# ---------------------------------------------------------------------------- prover
+class _G1Pipeline:
+    """Several G1 MSMs of different lengths in flight over ONE workspace: heads back to back on the caller's
+    stream, each tail on a side stream out of its own tail buffer (device.VarMsmPipeline generalised to a
+    length per submission)."""
+
+    def __init__(self, sizes, depth=2):
+        L = _lib.load()
+        self.depth = depth
+        self.ws_bytes = max(int(L.ozk_var_msm_head_workspace_bytes(n, 1)) for n in sizes)
+        self.tail_bytes = max(int(L.ozk_var_msm_tail_bytes(n, 1)) for n in sizes)
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device="cuda")
+        self.tails = [torch.empty(self.tail_bytes, dtype=torch.uint8, device="cuda") for _ in range(depth)]
+        self.side = torch.cuda.Stream()
+        self.head_done = [torch.cuda.Event() for _ in range(depth)]
+        self.tail_done = [torch.cuda.Event() for _ in range(depth)]
+        self.levels_done = []
+        for _ in range(depth):
+            ev = ctypes.c_void_p()
+            _lib.check(L.ozk_order_event_create(ctypes.byref(ev)))
+            self.levels_done.append(ev)
+        self.count = 0
+
+    def submit(self, d_prepared, d_scalars, n, out):
+        """out: uint8[192] tensor that receives the result (valid once the returned event has fired)."""
+        L = _lib.load()
+        slot = self.count % self.depth
+        main = torch.cuda.current_stream()
+        if self.count >= self.depth:
+            main.wait_event(self.tail_done[slot])
+        prev = self.levels_done[(self.count - 1) % self.depth] if self.count else None
+        _lib.check(L.ozk_var_msm_head_prepared_dev(_ptr(d_prepared), _ptr(d_scalars), n, 1, _ptr(self.ws), self.ws_bytes,
+                                                   _ptr(self.tails[slot]), self.tail_bytes, int(main.cuda_stream), prev))
+        self.head_done[slot].record(main)
+        self.side.wait_event(self.head_done[slot])
+        _lib.check(L.ozk_var_msm_tail_ordered_dev(n, 1, _ptr(self.tails[slot]), self.tail_bytes, _ptr(out),
+                                                  int(self.side.cuda_stream), self.levels_done[slot]))
+        self.tail_done[slot].record(self.side)
+        self.count += 1
+        return self.tail_done[slot]
+
+    def close(self):
+        if self.levels_done:
+            L = _lib.load()
+            torch.cuda.synchronize()
+            for ev in self.levels_done:
+                L.ozk_order_event_destroy(ev)
+            self.levels_done = []
+
+
+class Proof:
+    """zk_proof_systems/zkSNARK/objects/Proof.java: gA (G1), gB (G2), gC (G1) — wire-out bytes."""
+
+    def __init__(self, a, b, c):
+        self.g_a, self.g_b, self.g_c = a, b, c
+
+
+class SerialProver:
+    """SerialProver.prove (SerialProver.java:26-119) over a proving key resident in HBM.  Construct once per
+    key (prepares the bases), call prove() per witness."""
+
+    def __init__(self, pk: ProvingKey):
+        L = _lib.load()
+        self.pk = pk
+        r1cs = pk.r1cs
+        self.ni, self.nv = r1cs.num_inputs, r1cs.num_variables
+        self.nw = self.nv - self.ni
+        self.m = lowest_power_of_two(r1cs.num_constraints + self.ni)
+        ni, nw, m = self.ni, self.nw, self.m
+        assert pk.query_h.numel() == (m + 1) * 96 and pk.query_a.numel() == self.nv * 96
+
+        def prep(d_bases, n, type_):
+            nb = int(L.ozk_var_msm_prepared_bytes(n, type_))
+            out = torch.empty(nb, dtype=torch.uint8, device="cuda")
+            _lib.check(L.ozk_var_msm_prepare_dev(_ptr(d_bases), n, type_, _ptr(out), nb, _stream()))
+            return out
+
+        # A = alpha + sum z_i A_i(t) + r delta (SerialProver.java:105) = primary MSM + an auxiliary MSM whose
+        # base array carries alphaG1 and deltaG1 behind the auxiliary slice of query A (scalars 1 and r);
+        # B likewise with beta, delta and s (:108-110).  Same group elements, two scalar multiplications and
+        # four additions fewer on the critical path.
+        cat = torch.cat
+        self.qa_p = prep(pk.query_a[:ni * 96].contiguous(), ni, 1)
+        self.qa_w = prep(cat((pk.query_a[ni * 96:], pk.alpha_g1, pk.delta_g1)), nw + 2, 1)
+        self.qb1_p = prep(pk.query_b_g1[:ni * 96].contiguous(), ni, 1)
+        self.qb1_w = prep(cat((pk.query_b_g1[ni * 96:], pk.beta_g1, pk.delta_g1)), nw + 2, 1)
+        self.qb2_p = prep(pk.query_b_g2[:ni * 192].contiguous(), ni, 2)
+        self.qb2_w = prep(cat((pk.query_b_g2[ni * 192:], pk.beta_g2, pk.delta_g2)), nw + 2, 2)
+        self.qh = prep(pk.query_h, m + 1, 1)
+        self.dabc = prep(pk.delta_abc_g1, nw, 1)
+        torch.cuda.synchronize()
+        self.pipe = _G1Pipeline([ni, nw + 2, m + 1, nw, 5])
+        self.g2_ws_bytes = max(int(L.ozk_var_msm_workspace_bytes(n, 2)) for n in (ni, nw + 2))
+        self.g2_ws = torch.empty(self.g2_ws_bytes, dtype=torch.uint8, device="cuda")
+        self.s_g2 = torch.cuda.Stream()
+        self.fin_ws_bytes = int(L.ozk_var_msm_workspace_bytes(5, 1))
+        self.fin_ws = torch.empty(self.fin_ws_bytes, dtype=torch.uint8, device="cuda")
+        self.q_ws_bytes = int(L.ozk_qap_witness_workspace_bytes(m))
+        self.q_ws = torch.empty(self.q_ws_bytes, dtype=torch.uint8, device="cuda")
+        self.d_h = torch.empty((m + 1) * 32, dtype=torch.uint8, device="cuda")
+        # results: G1 MSM outputs (192 B each) and G2 outputs (384 B)
+        self.o1 = torch.zeros(8, 192, dtype=torch.uint8, device="cuda")
+        self.o2 = torch.zeros(3, 384, dtype=torch.uint8, device="cuda")
+        self.omega = ctypes.create_string_buffer(root_of_unity(m).to_bytes(32, "little"), 32)
+        self.g = ctypes.create_string_buffer(FR_MULT_GEN.to_bytes(32, "little"), 32)
+
+    def close(self):
+        self.pipe.close()
+
+    def prove(self, primary, auxiliary, seed: int = SEED, timing=None) -> Proof:
+        L = _lib.load()
+        pk, ni, nw, m = self.pk, self.ni, self.nw, self.m
+        T = {}
+        t0 = time.perf_counter()
+        full = list(primary) + list(auxiliary)
+        ev, m_ = constraint_evaluations(pk.r1cs, full)           # R1CStoQAP.java:143-160,195-199 (host)
+        assert m_ == m
+        T["evaluate_constraints_host_ms"] = (time.perf_counter() - t0) * 1e3
+        r = fr_random(seed)                                      # SerialProver.java:58-59
+        s = fr_random(seed)
+        t1 = time.perf_counter()
+        d_ev = [_dev_bytes(_le32(v)) for v in ev]
+        d_full = _dev_bytes(_le32(full))
+        tails = _dev_bytes(_le32([1, r, 1, s, 1, 1, s, r, (FR - r * s % FR) % FR]))
+        d_prim, d_aux = d_full[:ni * 32], d_full[ni * 32:]
+        d_aux_r = torch.cat((d_aux, tails[:64]))                 # auxiliary ++ [1, r]
+        d_aux_s = torch.cat((d_aux, tails[64:128]))              # auxiliary ++ [1, s]
+        d_fin_sc = tails[128:]                                   # [1, 1, s, r, -rs]
+        torch.cuda.synchronize()
+        T["marshal_upload_ms"] = (time.perf_counter() - t1) * 1e3
+        t2 = time.perf_counter()
+        main = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(main)
+        o1, o2 = self.o1, self.o2
+        # B in G2 (doubleMSM, SerialProver.java:82-88): own stream, nothing to wait for but the uploads
+        self.s_g2.wait_event(ready)
+        with torch.cuda.stream(self.s_g2):
+            st2 = _stream()
+            _lib.check(L.ozk_var_msm_prepared_dev(_ptr(self.qb2_p), _ptr(d_prim), ni, 2, _ptr(o2[0]), _ptr(self.g2_ws),
+                                                  self.g2_ws_bytes, st2))
+            _lib.check(L.ozk_var_msm_prepared_dev(_ptr(self.qb2_w), _ptr(d_aux_s), nw + 2, 2, _ptr(o2[1]),
+                                                  _ptr(self.g2_ws), self.g2_ws_bytes, st2))
+            _lib.check(L.ozk_points_sum_dev(_ptr(o2[:2]), 2, 2, _ptr(o2[2]), st2))   # B = primary + (aux + beta + s delta)
+            g2_done = torch.cuda.Event()
+            g2_done.record(self.s_g2)
+        # witness map (SerialProver.java:36-41): coefficientsH stay in HBM
+        _lib.check(L.ozk_qap_witness_dev(_ptr(d_ev[0]), _ptr(d_ev[1]), _ptr(d_ev[2]), m, ctypes.cast(self.omega, ctypes.c_void_p),
+                                         ctypes.cast(self.g, ctypes.c_void_p), _ptr(self.d_h), _ptr(self.q_ws),
+                                         self.q_ws_bytes, int(main.cuda_stream)))
+        p = self.pipe
+        evs = [p.submit(self.qa_p, d_prim, ni, o1[0]),           # :76-79 query A
+               p.submit(self.qa_w, d_aux_r, nw + 2, o1[1]),
+               p.submit(self.qb1_p, d_prim, ni, o1[2]),          # :82-88 query B, G1 half
+               p.submit(self.qb1_w, d_aux_s, nw + 2, o1[3]),
+               p.submit(self.qh, self.d_h, m + 1, o1[4]),        # :91-93 query H
+               p.submit(self.dabc, d_aux, nw, o1[5])]            # :98-101 deltaABC
+        for e in evs:
+            main.wait_event(e)
+        st = int(main.cuda_stream)
+        _lib.check(L.ozk_points_sum_dev(_ptr(o1[0:2]), 2, 1, _ptr(o1[6]), st))       # A
+        _lib.check(L.ozk_points_sum_dev(_ptr(o1[2:4]), 2, 1, _ptr(o1[7]), st))       # B in G1
+        # C = evaluationABC + H(t)Z(t)/delta + s A + r B1 - r s delta (:102,:114): one 5-term MSM
+        fin_bases = torch.cat((wire_out_to_in(o1[5], 1), wire_out_to_in(o1[4], 1), wire_out_to_in(o1[6], 1),
+                               wire_out_to_in(o1[7], 1), pk.delta_g1))
+        c_out = torch.zeros(192, dtype=torch.uint8, device="cuda")
+        _lib.check(L.ozk_var_msm_dev(_ptr(fin_bases), _ptr(d_fin_sc), 5, 1, _ptr(c_out), _ptr(self.fin_ws),
+                                     self.fin_ws_bytes, st))
+        main.wait_event(g2_done)
+        torch.cuda.synchronize()
+        T["gpu_ms"] = (time.perf_counter() - t2) * 1e3
+        proof = Proof(bytes(o1[6].cpu().numpy()), bytes(o2[2].cpu().numpy()), bytes(c_out.cpu().numpy()))
+        self._keep = (d_ev, d_full, tails, d_aux_r, d_aux_s, fin_bases)
+        if timing is not None:
+            timing.update(T)
+        return proof
+
+    def coefficients_h(self):
+        """coefficientsH of the last prove() (m + 1 ints), for checks."""
+        raw = bytes(self.d_h.cpu().numpy())
+        return [int.from_bytes(raw[32 * i:32 * i + 32], "little") for i in range(self.m + 1)]

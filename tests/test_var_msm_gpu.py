@@ -377,9 +377,20 @@ def test_glv_off_equals_glv_on(type_, monkeypatch):
     bases = bases[:n]
     scalars = [rng.randrange(o.R) for _ in range(n)]
     run = _run_g1 if type_ == 1 else _run_g2
+    from octopuszk_amd import lib
+    L = lib.load()
     on = run(scalars, bases)
+    glv_on = L.ozk_var_msm_glv(n)
     monkeypatch.setenv("OZK_MSM_GLV", "0")
-    off = run(scalars, bases)
+    assert L.ozk_var_msm_glv(n) == glv_on == 1    # tuning variables are cached per process ...
+    L.ozk_tuning_reload()                          # ... until a reload (include/ozk.h)
+    try:
+        assert L.ozk_var_msm_glv(n) == 0
+        off = run(scalars, bases)
+    finally:
+        monkeypatch.delenv("OZK_MSM_GLV")
+        L.ozk_tuning_reload()
+    assert L.ozk_var_msm_glv(n) == 1
     assert on == off
 
 
