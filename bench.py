@@ -44,6 +44,14 @@ def rand_scalars(n, seed):
     return b.reshape(-1)
 
 
+def base_seed(rank):
+    return 2 + (rank << 32)
+
+
+def scalar_seed(rank):
+    return 1 + rank
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,8 +105,8 @@ def main():
     L = ozk.load()
     n = 1 << args.logn
     # inputs: rank r owns pairs [r*n, (r+1)*n) of the global MSM (distinct seeds per rank)
-    bases = dev.gen_g1_bases(n, seed=2 + (rank << 32))
-    sc_host = rand_scalars(n, 1 + rank)
+    bases = dev.gen_g1_bases(n, seed=base_seed(rank))
+    sc_host = rand_scalars(n, scalar_seed(rank))
     scalars = torch.from_numpy(sc_host).cuda()
     pipe = dev.VarMsmPipeline(n, 1, depth=max(1, args.in_flight))
     msm_bases = pipe.prepare(bases) if args.prepared else bases
@@ -236,6 +244,7 @@ def main():
                            "prepared_bases": bool(args.prepared),
                            "msms_in_flight": max(1, args.in_flight), "schedule": args.schedule,
                            "single_msm_latency_ms": round(single_ms, 3),
+                           "result_hex": result_bytes.hex(),
                            "parallelism": "index-range shard x%d, RCCL all-gather of 192-B partials + HIP point sum" % world},
                 "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)

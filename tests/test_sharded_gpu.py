@@ -1,0 +1,109 @@
+"""V10 on hardware (VERDICT r1 "missing" 2): the index-range-sharded variable-base MSM with the REAL per-rank HIP
+pipeline — two ranks sharing cuda:0, exchange over gloo (RCCL refuses two ranks on one device) — against the C
+oracle on the WHOLE input.  VariableBaseMSM.distributedMSM semantics (VariableBaseMSM.java:775-786):
+mapPartitions(serialMSMPartition) -> reduce(GroupT::add)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import bn254 as o
+from oracle import coracle
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, type_, bases_wire, scalars_wire, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from octopuszk_amd import device as dev
+    from octopuszk_amd import distributed as D
+    pt = 96 if type_ == 1 else 192
+    lo, hi = D.shard_range(n, rank, world)
+    d_b = torch.from_numpy(np.frombuffer(bases_wire[pt * lo:pt * hi], dtype=np.uint8).copy()).cuda()
+    d_s = torch.from_numpy(np.frombuffer(scalars_wire[32 * lo:32 * hi], dtype=np.uint8).copy()).cuda()
+    ws = dev.VarMsmWorkspace(hi - lo, type_)
+
+    def gather_cpu(partial, group=None):   # gloo moves host tensors
+        out = [torch.empty(partial.numel(), dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(out, partial.cpu().contiguous())
+        return torch.cat(out).cuda()
+
+    D.all_gather_partials = gather_cpu
+    out = D.gpu_var_msm(ws, d_b, d_s)         # HIP MSM on the slice + all-gather + HIP point sum
+    torch.cuda.synchronize()
+    q.put((rank, bytes(out.cpu().numpy())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,world", [(4096, 2), (5001, 3)])
+def test_sharded_g1_msm_equals_oracle_on_the_whole_input(n, world):
+    rng = np.random.default_rng(n)
+    G = o.G1
+    pts = [G.to_affine(G.mul(G.one, int(k))) for k in rng.integers(1, 1 << 62, size=64)]
+    bw = b"".join(o.g1_to_wire(pts[i % 64]) for i in range(n))
+    sc = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    sc[:, 31] &= 0x1F
+    sw = sc.tobytes()
+    want = coracle.pippenger_g1(bw, sw, n)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, 1, bw, sw, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert got[r] == want, r
+
+
+def test_bench_two_ranks_on_one_gpu_result_is_the_global_msm():
+    """bench.py's N = 2 path on one GPU (OZK_BENCH_REHEARSAL=1: gloo instead of RCCL): the contract line, and
+    the printed result equals (sum over BOTH ranks' inputs of s_i k_i) G — bench.py's bases are k_i G with
+    k_i = splitmix64(seed + i), so the expected point is exact integer arithmetic plus one scalar multiplication."""
+    from octopuszk_amd import device as dev
+    logn = 12
+    env = dict(os.environ, OZK_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4",
+           "--warmup", "1", "--logn", str(logn)]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and d["unit"] == "Mscalar-mul/s"
+    assert d["value"] > 0 and d["cpu_baseline"] is None and d["roofline"]["bound"] == "hbm"
+    assert "x2" in d["config"]["parallelism"]
+    n = 1 << logn
+    sys.path.insert(0, ROOT)
+    import bench
+    acc = 0
+    for rank in range(2):
+        ks = dev.gen_base_logs(n, bench.base_seed(rank))
+        sc = bench.rand_scalars(n, bench.scalar_seed(rank)).reshape(n, 32)
+        acc += sum(k * int.from_bytes(s.tobytes(), "little") for k, s in zip(ks, sc))
+    want = o.g1_out_le(o.G1.to_affine(o.G1.mul(o.G1.one, acc % o.R)))
+    assert bytes.fromhex(d["config"]["result_hex"]) == want
