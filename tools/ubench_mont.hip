@@ -1,0 +1,133 @@
+// Variants of the 29-bit-limb Montgomery multiplication measured at the occupancy of the level-1 kernel
+// (3 waves per SIMD): how much of a multiplication is NOT v_mad_u64_u32, and what removing it buys.
+//   A  plain C (what fp29.cuh compiles to: hipcc gives every column its own accumulator and then ripples
+//      the carries with one 64-bit shift + one 64-bit add per column)
+//   B  the carry folded into the first multiply-add of the next column (asm MADs, 64-bit shift)
+//   C  as B, the 64-bit shift replaced by v_alignbit_b32 + v_lshrrev_b32 (off the 64-bit pipe)
+// Build: hipcc --offload-arch=gfx950 -O3 ubench_mont.hip -o ubench_mont
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+typedef uint32_t u32; typedef uint64_t u64;
+#define MASK 0x1fffffffu
+struct Fe { u32 l[9]; };
+__device__ constexpr u32 PL[9] = {0x187cfd47,0x10460b6,0x1c72a34f,0x2d522d0,0x1585d978,0x2db40c0,0xa6e141,0xe5c2634,0x30644e};
+constexpr u32 PINV = 0x1f5ba9b9u;
+
+__device__ __forceinline__ u64 mad(u32 a, u32 b, u64 c){ return (u64)a*b + c; }
+__device__ __forceinline__ Fe mul_A(const Fe& a, const Fe& b){
+  u64 acc=0; u32 m[9]; Fe r;
+  #pragma unroll
+  for(int k=0;k<9;k++){
+    #pragma unroll
+    for(int i=0;i<=k;i++) acc = mad(a.l[i], b.l[k-i], acc);
+    #pragma unroll
+    for(int i=0;i<k;i++) acc = mad(m[i], PL[k-i], acc);
+    m[k] = ((u32)acc * PINV) & MASK;
+    acc = mad(m[k], PL[0], acc);
+    acc >>= 29;
+  }
+  #pragma unroll
+  for(int k=9;k<17;k++){
+    #pragma unroll
+    for(int i=k-8;i<9;i++) acc = mad(a.l[i], b.l[k-i], acc);
+    #pragma unroll
+    for(int i=k-8;i<9;i++) acc = mad(m[i], PL[k-i], acc);
+    r.l[k-9] = (u32)acc & MASK; acc >>= 29;
+  }
+  r.l[8]=(u32)acc;
+  return r;
+}
+// asm multiply-add: acc += a*b, scalar carry-out discarded into vcc
+__device__ __forceinline__ void amad(u64& acc, u32 a, u32 b){
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
+}
+__device__ __forceinline__ void amads(u64& acc, u32 a, u32 s){   // s: wave-uniform constant in an SGPR
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "s"(s) : "vcc");
+}
+template<bool ALIGNBIT>
+__device__ __forceinline__ u64 shr29(u64 acc){
+  if constexpr (!ALIGNBIT) return acc >> 29;
+  u32 lo=(u32)acc, hi=(u32)(acc>>32), nlo, nhi;
+  asm("v_alignbit_b32 %0, %1, %2, 29" : "=v"(nlo) : "v"(hi), "v"(lo));
+  nhi = hi >> 29;
+  return ((u64)nhi<<32)|nlo;
+}
+template<bool ALIGNBIT>
+__device__ __forceinline__ Fe mul_BC(const Fe& a, const Fe& b){
+  u64 acc=0; u32 m[9]; Fe r;
+  #pragma unroll
+  for(int k=0;k<9;k++){
+    #pragma unroll
+    for(int i=0;i<=k;i++) amad(acc, a.l[i], b.l[k-i]);
+    #pragma unroll
+    for(int i=0;i<k;i++) amads(acc, m[i], PL[k-i]);
+    m[k] = ((u32)acc * PINV) & MASK;
+    amads(acc, m[k], PL[0]);
+    acc = shr29<ALIGNBIT>(acc);
+  }
+  #pragma unroll
+  for(int k=9;k<17;k++){
+    #pragma unroll
+    for(int i=k-8;i<9;i++) amad(acc, a.l[i], b.l[k-i]);
+    #pragma unroll
+    for(int i=k-8;i<9;i++) amads(acc, m[i], PL[k-i]);
+    r.l[k-9] = (u32)acc & MASK; acc = shr29<ALIGNBIT>(acc);
+  }
+  r.l[8]=(u32)acc;
+  return r;
+}
+template<int V> __device__ __forceinline__ Fe mulv(const Fe& a, const Fe& b){
+  if constexpr (V==0) return mul_A(a,b);
+  else if constexpr (V==1) return mul_BC<false>(a,b);
+  else return mul_BC<true>(a,b);
+}
+// NCH independent chains per lane; dynamic LDS request limits the occupancy to WPS waves per SIMD
+template<int V, int NCH>
+__global__ void __launch_bounds__(256) k_mont(u64* out, u32 a, u32 b, int iters){
+  Fe x[NCH], y;
+  for(int c=0;c<NCH;c++) for(int j=0;j<9;j++) x[c].l[j]=(threadIdx.x*2654435761u+j*40503u+a+c)&MASK;
+  for(int j=0;j<9;j++) y.l[j]=(threadIdx.x*40503u+j*2654435761u+b)&MASK;
+  for(int t=0;t<iters;t++){
+    #pragma unroll
+    for(int c=0;c<NCH;c++) x[c]=mulv<V>(x[c],y);
+  }
+  u32 s=0; for(int c=0;c<NCH;c++) for(int j=0;j<9;j++) s^=x[c].l[j]; out[blockIdx.x*blockDim.x+threadIdx.x]=s;
+}
+template<class F> double timeit(F f){
+  hipEvent_t e0,e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  f(); hipDeviceSynchronize();
+  hipEventRecord(e0); for(int r=0;r<5;r++) f(); hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms,e0,e1); return ms/5.0;
+}
+template<int V, int NCH> void run(const char* name, u64* out, int CU){
+  // correctness vs variant A on one block
+  for(int w : {1,2,3,4,8}){
+    int blocks=CU*w, iters=256;
+    double ms=timeit([&]{ hipLaunchKernelGGL((k_mont<V,NCH>), dim3(blocks), dim3(256), 0, 0, out, 12345u, 678u, iters); });
+    double muls=(double)blocks*256*iters*NCH; double cyc = ms*1e-3*2.4e9*(CU*4.0)/(muls/64.0);
+    printf("%-28s x%d waves/SIMD=%d %.3f ms  %.2f Gmul/s  ~%.0f cyc/wave-mul\n", name, NCH, w, ms, muls/ms*1e-6, cyc);
+  }
+}
+int main(){
+  hipDeviceProp_t prop; hipGetDeviceProperties(&prop,0);
+  int CU=prop.multiProcessorCount;
+  u64 *o0,*o1; hipMalloc(&o0, sizeof(u64)*CU*16*256); hipMalloc(&o1, sizeof(u64)*CU*16*256);
+  // parity of the variants (same inputs -> same checksum words)
+  u64 h[3][256];
+  for(int v=0;v<3;v++){
+    if(v==0) hipLaunchKernelGGL((k_mont<0,1>), dim3(1), dim3(256), 0, 0, o0, 12345u, 678u, 7);
+    if(v==1) hipLaunchKernelGGL((k_mont<1,1>), dim3(1), dim3(256), 0, 0, o0, 12345u, 678u, 7);
+    if(v==2) hipLaunchKernelGGL((k_mont<2,1>), dim3(1), dim3(256), 0, 0, o0, 12345u, 678u, 7);
+    hipMemcpy(h[v], o0, sizeof(u64)*256, hipMemcpyDeviceToHost);
+  }
+  int bad=0; for(int i=0;i<256;i++) if(h[0][i]!=h[1][i]||h[0][i]!=h[2][i]) bad++;
+  printf("variant parity: %s\n", bad? "MISMATCH":"ok");
+  run<0,1>("A plain C", o0, CU);
+  run<1,1>("B chained carry", o0, CU);
+  run<2,1>("C chained + alignbit", o0, CU);
+  run<0,2>("A plain C", o0, CU);
+  run<1,2>("B chained carry", o0, CU);
+  run<2,2>("C chained + alignbit", o0, CU);
+  return 0;
+}
