@@ -53,6 +53,10 @@ int ozk_device_count(void);
 /* The OZK_* tuning environment variables are read once per process and cached (a plan must not change
  * between the workspace-size query and the run); tests and tuning scripts call this after changing one. */
 int ozk_tuning_reload(void);
+/* The `*_host` entry points keep their streams, device arena and pinned staging buffers in a per-device
+ * pool between calls (the reference allocates and frees inside every native call,
+ * algebra_msm_VariableBaseMSM.cu:1292-1303,1405-1409).  This gives everything back. */
+int ozk_host_cache_release(void);
 
 /* ---------------- VariableBaseMSM ---------------------------------------
  * replaces Java_algebra_msm_VariableBaseMSM_variableBaseSerialMSMNativeHelper

@@ -18,7 +18,7 @@
 //    between stages (value bounds are tracked at compile time), reads/writes HBM once,
 //    in >= 128-byte contiguous segments.  The bit reversal is fused into the first pass.
 #include "curve.cuh"
-#include "ozk_common.h"
+#include "host_ctx.h"
 
 namespace ozk {
 
@@ -510,68 +510,42 @@ int ozk_qap_witness_host(const uint8_t* A, const uint8_t* B, const uint8_t* C, i
   if (!A || !B || !C || !omega || !g || !H) return fail(OZK_E_INVALID, "null pointer argument");
   if (m <= 1 || (m & (m - 1)) || m > (1 << 28))
     return fail(OZK_E_INVALID, "domain size %d is not a power of two in [2, 2^28]", m);
-  int rc = select_device(task_id);
-  if (rc) return rc;
   const size_t vb = (size_t)m * 32, hb = ((size_t)m + 1) * 32;
-  const size_t vpad = (vb + 255) & ~(size_t)255, hpad = (hb + 255) & ~(size_t)255;
+  const size_t vpad = pad256(vb), hpad = pad256(hb);
   const size_t wsb = ozk_qap_witness_workspace_bytes(m);
-  uint8_t* d = nullptr;
-  hipStream_t st = nullptr;
-  OZK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-  hipError_t e = hipMalloc((void**)&d, 3 * vpad + hpad + wsb + 1024);
-  if (e != hipSuccess) {
-    hipStreamDestroy(st);
-    return fail(OZK_E_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
-  }
-  uint8_t *dA = d, *dB = d + vpad, *dC = d + 2 * vpad, *dH = d + 3 * vpad, *dW = d + 3 * vpad + hpad;
-  rc = OZK_OK;
-  do {
-    if ((e = hipMemcpyAsync(dA, A, vb, hipMemcpyHostToDevice, st)) != hipSuccess) break;
-    if ((e = hipMemcpyAsync(dB, B, vb, hipMemcpyHostToDevice, st)) != hipSuccess) break;
-    if ((e = hipMemcpyAsync(dC, C, vb, hipMemcpyHostToDevice, st)) != hipSuccess) break;
-    rc = qap_witness_dev(dA, dB, dC, m, omega, g, dH, dW, wsb, st);
-    if (rc) break;
-    if ((e = hipMemcpyAsync(H, dH, hb, hipMemcpyDeviceToHost, st)) != hipSuccess) break;
-    e = hipStreamSynchronize(st);
-  } while (0);
-  hipFree(d);
-  hipStreamDestroy(st);
+  CtxGuard guard;
+  int rc = ctx_acquire(task_id, &guard.c);
   if (rc) return rc;
-  if (e != hipSuccess) return fail(OZK_E_NO_DEVICE, "HIP failure in qap_witness_host: %s", hipGetErrorString(e));
-  return OZK_OK;
+  HostCtx* c = guard.c;
+  if ((rc = ctx_reserve(c, 3 * vpad + hpad + wsb + 1024))) return rc;
+  uint8_t* d = c->arena;
+  uint8_t *dA = d, *dB = d + vpad, *dC = d + 2 * vpad, *dH = d + 3 * vpad, *dW = d + 3 * vpad + hpad;
+  hipStream_t st = c->st[0];
+  if ((rc = staged_h2d(c, dA, A, vb, st))) return rc;
+  if ((rc = staged_h2d(c, dB, B, vb, st))) return rc;
+  if ((rc = staged_h2d(c, dC, C, vb, st))) return rc;
+  if ((rc = qap_witness_dev(dA, dB, dC, m, omega, g, dH, dW, wsb, st))) return rc;
+  return staged_d2h(c, H, dH, hb, st);
 }
 
 static int fft_host(const uint8_t* in, int32_t n, const uint8_t* omega, int32_t task_id, uint8_t* out, int out_stride) {
   if (!in || !omega || !out) return fail(OZK_E_INVALID, "null pointer argument");
   if (n <= 0 || (n & (n - 1)) || n > (1 << 28))
     return fail(OZK_E_INVALID, "FFT size %d is not a power of two in [1, 2^28]", n);
-  int rc = select_device(task_id);
-  if (rc) return rc;
   const size_t in_bytes = (size_t)n * 32, out_bytes = (size_t)n * 4 * out_stride;
   const size_t wsb = ozk_fft_workspace_bytes(n);
-  uint8_t* d = nullptr;
-  hipStream_t st = nullptr;
-  OZK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-  hipError_t e = hipMalloc((void**)&d, in_bytes + out_bytes + wsb + 1024);
-  if (e != hipSuccess) {
-    hipStreamDestroy(st);
-    return fail(OZK_E_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
-  }
-  uint8_t* d_out = d + ((in_bytes + 255) & ~(size_t)255);
-  uint8_t* d_ws = d_out + ((out_bytes + 255) & ~(size_t)255);
-  rc = OZK_OK;
-  do {
-    if ((e = hipMemcpyAsync(d, in, in_bytes, hipMemcpyHostToDevice, st)) != hipSuccess) break;
-    rc = fft_dev(d, n, omega, d_out, d_ws, wsb, st, out_stride);
-    if (rc) break;
-    if ((e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, st)) != hipSuccess) break;
-    e = hipStreamSynchronize(st);
-  } while (0);
-  hipFree(d);
-  hipStreamDestroy(st);
+  CtxGuard g;
+  int rc = ctx_acquire(task_id, &g.c);
   if (rc) return rc;
-  if (e != hipSuccess) return fail(OZK_E_NO_DEVICE, "HIP failure in fft_host: %s", hipGetErrorString(e));
-  return OZK_OK;
+  HostCtx* c = g.c;
+  if ((rc = ctx_reserve(c, pad256(in_bytes) + pad256(out_bytes) + wsb + 1024))) return rc;
+  uint8_t* d = c->arena;
+  uint8_t* d_out = d + pad256(in_bytes);
+  uint8_t* d_ws = d_out + pad256(out_bytes);
+  hipStream_t st = c->st[0];
+  if ((rc = staged_h2d(c, d, in, in_bytes, st))) return rc;
+  if ((rc = fft_dev(d, n, omega, d_out, d_ws, wsb, st, out_stride))) return rc;
+  return staged_d2h(c, out, d_out, out_bytes, st);
 }
 
 int ozk_fft_host(const uint8_t* in, int32_t n, const uint8_t* omega, int32_t task_id, uint8_t* out) {

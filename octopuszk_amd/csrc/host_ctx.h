@@ -1,0 +1,59 @@
+// Host-side resources of the JNI-shaped (`*_host`) entry points, cached across calls.
+//
+// The reference allocates, copies synchronously from pageable memory and frees inside every native call
+// (algebra_msm_VariableBaseMSM.cu:1260-1265,1292-1303,1405-1409); round 1 of this library did the same with
+// a stream created and destroyed per call.  Measured on the MI355X box (profiles/r02_h2d_probe.txt):
+// creating a stream costs up to 20 ms, a cold pageable hipMemcpyAsync of 128 MiB 11 ms against 2.3 ms
+// once the runtime has the pages pinned — so the per-call cost was dominated by set-up, and varied 4x
+// from box to box.  Here:
+//   * a POOL of contexts per device (a caller takes one for the duration of its call, so concurrent Spark
+//     task threads — SURVEY.md §8b "Threading" — never share a stream or a buffer, and never serialise on
+//     a device-wide hipFree): two streams, a few events, a grow-only device arena;
+//   * uploads / downloads staged through a ring of pinned 16 MiB buffers filled by a small pool of copy
+//     threads (48 GB/s from memory the runtime has never seen, against 57 GB/s for pinned memory), the DMA of
+//     chunk k overlapping the memcpy of chunk k + 1, and the kernels that only need the first buffers
+//     (digit extraction, base conversion) overlapping the rest of the upload.
+// Nothing here computes; ozk_host_cache_release() gives everything back.
+#pragma once
+#include "ozk_common.h"
+
+namespace ozk {
+
+constexpr size_t STAGE_BYTES = (size_t)16 << 20;
+constexpr int STAGE_RING = 3;
+
+struct HostCtx {
+  int device = -1;
+  hipStream_t st[2] = {nullptr, nullptr};  // [0] compute (+ its copies), [1] second engine (G2 / uploads)
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  uint8_t* arena = nullptr;  // device, grow-only
+  size_t arena_cap = 0;
+  uint8_t* stage[STAGE_RING] = {nullptr, nullptr, nullptr};  // pinned host
+  hipEvent_t stage_free[STAGE_RING] = {nullptr, nullptr, nullptr};
+  bool stage_busy[STAGE_RING] = {false, false, false};
+  int stage_next = 0;
+  HostCtx* next = nullptr;
+};
+
+// Takes a context for `task_id % device_count` (creating one when the pool is empty) and makes that device
+// current for the calling thread.  Returns OZK_OK or an error code (message in ozk_last_error()).
+int ctx_acquire(int task_id, HostCtx** out);
+void ctx_release(HostCtx* c);
+// device arena of at least `bytes` (contents are NOT preserved when it grows)
+int ctx_reserve(HostCtx* c, size_t bytes);
+// pageable host -> device on `st`, staged through the pinned ring; returns once every byte has been handed to
+// the DMA engine (the copies themselves complete in stream order)
+int staged_h2d(HostCtx* c, void* d_dst, const void* h_src, size_t bytes, hipStream_t st);
+// device -> pageable host, staged; synchronises `st` (the data is in h_dst on return)
+int staged_d2h(HostCtx* c, void* h_dst, const void* d_src, size_t bytes, hipStream_t st);
+
+struct CtxGuard {  // release on scope exit
+  HostCtx* c = nullptr;
+  ~CtxGuard() {
+    if (c) ctx_release(c);
+  }
+};
+
+inline size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+}  // namespace ozk

@@ -1,0 +1,269 @@
+// Context pool, pinned staging ring and copy threads of the `*_host` entry points (host_ctx.h).
+#include "host_ctx.h"
+
+#include <atomic>
+
+namespace ozk {
+
+// ---------------------------------------------------------------- copy threads
+// A handful of helper threads that do nothing but memcpy between caller memory and the pinned ring: one
+// core moves ~12 GB/s, the PCIe link 57 GB/s.  Started on first use; they sleep on a condition variable.
+namespace {
+constexpr int COPY_HELPERS = 3;  // + the calling thread
+constexpr int COPY_QUEUE = 64;
+struct CopyTask {
+  void* dst;
+  const void* src;
+  size_t len;
+  std::atomic<int>* pending;
+};
+struct CopyPool {
+  pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+  pthread_cond_t cv = PTHREAD_COND_INITIALIZER;
+  CopyTask q[COPY_QUEUE];
+  int head = 0, count = 0;
+  bool started = false, failed = false;
+  pthread_t th[COPY_HELPERS];
+};
+CopyPool g_copy;
+
+bool copy_pop(CopyTask* t, bool wait) {
+  pthread_mutex_lock(&g_copy.mu);
+  while (g_copy.count == 0) {
+    if (!wait) {
+      pthread_mutex_unlock(&g_copy.mu);
+      return false;
+    }
+    pthread_cond_wait(&g_copy.cv, &g_copy.mu);
+  }
+  *t = g_copy.q[g_copy.head];
+  g_copy.head = (g_copy.head + 1) % COPY_QUEUE;
+  g_copy.count--;
+  pthread_mutex_unlock(&g_copy.mu);
+  return true;
+}
+void* copy_worker(void*) {
+  for (;;) {
+    CopyTask t;
+    copy_pop(&t, true);
+    memcpy(t.dst, t.src, t.len);
+    t.pending->fetch_sub(1, std::memory_order_release);
+  }
+  return nullptr;
+}
+void copy_start_locked() {
+  if (g_copy.started || g_copy.failed) return;
+  for (int i = 0; i < COPY_HELPERS; i++) {
+    if (pthread_create(&g_copy.th[i], nullptr, copy_worker, nullptr) != 0) {
+      g_copy.failed = true;  // (already running helpers keep working; the caller copies the rest itself)
+      return;
+    }
+    pthread_detach(g_copy.th[i]);
+  }
+  g_copy.started = true;
+}
+void parallel_memcpy(void* dst, const void* src, size_t len) {
+  static const int helpers = env_int("OZK_COPY_HELPERS", COPY_HELPERS);   // 0: the calling thread copies alone
+  if (len < ((size_t)1 << 20) || helpers <= 0) {
+    memcpy(dst, src, len);
+    return;
+  }
+  const int parts = (helpers < COPY_HELPERS ? helpers : COPY_HELPERS) + 1;
+  const size_t per = ((len + parts - 1) / parts + 63) & ~(size_t)63;
+  std::atomic<int> pending(0);
+  pthread_mutex_lock(&g_copy.mu);
+  copy_start_locked();
+  int queued = 0;
+  if (g_copy.started) {
+    for (int p = 1; p < parts; p++) {
+      const size_t o = (size_t)p * per;
+      if (o >= len || g_copy.count == COPY_QUEUE) break;
+      const size_t l = (len - o < per) ? (len - o) : per;
+      pending.fetch_add(1, std::memory_order_relaxed);
+      g_copy.q[(g_copy.head + g_copy.count) % COPY_QUEUE] = CopyTask{(uint8_t*)dst + o, (const uint8_t*)src + o, l, &pending};
+      g_copy.count++;
+      queued++;
+    }
+    if (queued) pthread_cond_broadcast(&g_copy.cv);
+  }
+  pthread_mutex_unlock(&g_copy.mu);
+  const size_t mine = queued ? per : len;   // the queued parts are 1 .. queued; the rest is this thread's
+  memcpy(dst, src, mine < len ? mine : len);
+  const size_t done_upto = (size_t)(queued + 1) * per;
+  if (queued && done_upto < len) memcpy((uint8_t*)dst + done_upto, (const uint8_t*)src + done_upto, len - done_upto);
+  // help with whatever is still queued (ours or another caller's), then wait for ours
+  CopyTask t;
+  while (pending.load(std::memory_order_acquire) != 0) {
+    if (copy_pop(&t, false)) {
+      memcpy(t.dst, t.src, t.len);
+      t.pending->fetch_sub(1, std::memory_order_release);
+    } else {
+      sched_yield();
+    }
+  }
+}
+}  // namespace
+
+// ---------------------------------------------------------------- context pool
+namespace {
+constexpr int MAX_DEVICES = 64;
+pthread_mutex_t g_pool_mu = PTHREAD_MUTEX_INITIALIZER;
+HostCtx* g_free[MAX_DEVICES] = {nullptr};
+
+void ctx_destroy(HostCtx* c) {
+  hipSetDevice(c->device);
+  for (auto& s : c->st)
+    if (s) {
+      hipStreamSynchronize(s);
+      hipStreamDestroy(s);
+    }
+  for (auto& e : c->ev)
+    if (e) hipEventDestroy(e);
+  for (int i = 0; i < STAGE_RING; i++) {
+    if (c->stage[i]) hipHostFree(c->stage[i]);
+    if (c->stage_free[i]) hipEventDestroy(c->stage_free[i]);
+  }
+  if (c->arena) hipFree(c->arena);
+  delete c;
+}
+}  // namespace
+
+int ctx_acquire(int task_id, HostCtx** out) {
+  int rc = select_device(task_id);
+  if (rc) return rc;
+  int dev = 0;
+  OZK_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= MAX_DEVICES) return fail(OZK_E_INTERNAL, "device index %d out of range", dev);
+  pthread_mutex_lock(&g_pool_mu);
+  HostCtx* c = g_free[dev];
+  if (c) g_free[dev] = c->next;
+  pthread_mutex_unlock(&g_pool_mu);
+  if (!c) {
+    c = new HostCtx();
+    c->device = dev;
+    hipError_t e = hipSuccess;
+    for (auto& s : c->st)
+      if (e == hipSuccess) e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    for (auto& v : c->ev)
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&v, hipEventDisableTiming);
+    for (int i = 0; i < STAGE_RING; i++) {
+      if (e == hipSuccess) e = hipHostMalloc((void**)&c->stage[i], STAGE_BYTES, hipHostMallocDefault);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&c->stage_free[i], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) {
+      ctx_destroy(c);
+      return fail(e == hipErrorOutOfMemory ? OZK_E_NOMEM : OZK_E_NO_DEVICE, "creating a host context failed: %s",
+                  hipGetErrorString(e));
+    }
+  }
+  c->next = nullptr;
+  *out = c;
+  return OZK_OK;
+}
+
+void ctx_release(HostCtx* c) {
+  if (!c) return;
+  pthread_mutex_lock(&g_pool_mu);
+  c->next = g_free[c->device];
+  g_free[c->device] = c;
+  pthread_mutex_unlock(&g_pool_mu);
+}
+
+int ctx_reserve(HostCtx* c, size_t bytes) {
+  if (bytes <= c->arena_cap) return OZK_OK;
+  // everything queued on this context's streams may still use the old arena
+  OZK_HIP(hipStreamSynchronize(c->st[0]));
+  OZK_HIP(hipStreamSynchronize(c->st[1]));
+  if (c->arena) OZK_HIP(hipFree(c->arena));
+  c->arena = nullptr;
+  c->arena_cap = 0;
+  const size_t want = pad256(bytes + bytes / 8);  // some slack: sizes creep with n
+  hipError_t e = hipMalloc((void**)&c->arena, want);
+  if (e != hipSuccess) return fail(OZK_E_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+  c->arena_cap = want;
+  return OZK_OK;
+}
+
+static int stage_wait(HostCtx* c, int b) {
+  if (c->stage_busy[b]) {
+    OZK_HIP(hipEventSynchronize(c->stage_free[b]));
+    c->stage_busy[b] = false;
+  }
+  return OZK_OK;
+}
+
+int staged_h2d(HostCtx* c, void* d_dst, const void* h_src, size_t bytes, hipStream_t st) {
+  size_t off = 0;
+  while (off < bytes) {
+    const size_t len = (bytes - off < STAGE_BYTES) ? (bytes - off) : STAGE_BYTES;
+    const int b = c->stage_next;
+    c->stage_next = (b + 1) % STAGE_RING;
+    int rc = stage_wait(c, b);
+    if (rc) return rc;
+    parallel_memcpy(c->stage[b], (const uint8_t*)h_src + off, len);
+    OZK_HIP(hipMemcpyAsync((uint8_t*)d_dst + off, c->stage[b], len, hipMemcpyHostToDevice, st));
+    OZK_HIP(hipEventRecord(c->stage_free[b], st));
+    c->stage_busy[b] = true;
+    off += len;
+  }
+  return OZK_OK;
+}
+
+int staged_d2h(HostCtx* c, void* h_dst, const void* d_src, size_t bytes, hipStream_t st) {
+  if (bytes <= ((size_t)1 << 16)) {  // a result point: one small synchronous copy
+    OZK_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, st));
+    OZK_HIP(hipStreamSynchronize(st));
+    return OZK_OK;
+  }
+  const size_t nchunks = (bytes + STAGE_BYTES - 1) / STAGE_BYTES;
+  int buf_of[STAGE_RING];
+  auto issue = [&](size_t k) -> int {
+    const int b = c->stage_next;
+    c->stage_next = (b + 1) % STAGE_RING;
+    int rc = stage_wait(c, b);
+    if (rc) return rc;
+    const size_t off = k * STAGE_BYTES;
+    const size_t len = (bytes - off < STAGE_BYTES) ? (bytes - off) : STAGE_BYTES;
+    OZK_HIP(hipMemcpyAsync(c->stage[b], (const uint8_t*)d_src + off, len, hipMemcpyDeviceToHost, st));
+    OZK_HIP(hipEventRecord(c->stage_free[b], st));
+    c->stage_busy[b] = true;
+    buf_of[k % STAGE_RING] = b;
+    return OZK_OK;
+  };
+  size_t issued = 0;
+  for (; issued < nchunks && issued < (size_t)STAGE_RING; issued++) {
+    int rc = issue(issued);
+    if (rc) return rc;
+  }
+  for (size_t k = 0; k < nchunks; k++) {
+    const int b = buf_of[k % STAGE_RING];
+    int rc = stage_wait(c, b);
+    if (rc) return rc;
+    const size_t off = k * STAGE_BYTES;
+    const size_t len = (bytes - off < STAGE_BYTES) ? (bytes - off) : STAGE_BYTES;
+    parallel_memcpy((uint8_t*)h_dst + off, c->stage[b], len);
+    if (issued < nchunks) {
+      rc = issue(issued++);
+      if (rc) return rc;
+    }
+  }
+  return OZK_OK;
+}
+
+}  // namespace ozk
+
+extern "C" int ozk_host_cache_release(void) {
+  using namespace ozk;
+  pthread_mutex_lock(&g_pool_mu);
+  for (int d = 0; d < MAX_DEVICES; d++) {
+    HostCtx* c = g_free[d];
+    g_free[d] = nullptr;
+    while (c) {
+      HostCtx* n = c->next;
+      ctx_destroy(c);
+      c = n;
+    }
+  }
+  pthread_mutex_unlock(&g_pool_mu);
+  return OZK_OK;
+}

@@ -27,7 +27,7 @@
 #include "fq2.cuh"
 #include "glv.cuh"
 #include "msm_var.cuh"  // RunAccLds: the LDS-resident XYZZ accumulator (G2)
-#include "ozk_common.h"
+#include "host_ctx.h"
 
 namespace ozk {
 
@@ -414,16 +414,6 @@ static int fixed_batch_dev(int outerc, int ws, int n, const void* d_base, const 
   return OZK_OK;
 }
 
-// RAII-less helper for the host variants
-struct DevBuf {
-  uint8_t* p = nullptr;
-  hipStream_t st = nullptr;
-  ~DevBuf() {
-    if (p) hipFree(p);
-    if (st) hipStreamDestroy(st);
-  }
-};
-
 }  // namespace ozk
 
 using namespace ozk;
@@ -466,23 +456,24 @@ static int fixed_batch_host(int32_t outerc, int32_t ws, int32_t n, const uint8_t
   if (!base || !scalars || !out) return fail(OZK_E_INVALID, "null pointer argument");
   int rc = fb_check_args(outerc, ws, n);
   if (rc) return rc;
-  if ((rc = select_device(task_id))) return rc;
   const bool g1 = bn_type == OZK_G1;
   const size_t base_bytes = g1 ? 96 : 192, sc_bytes = (size_t)n * 32;
   const size_t out_bytes = (size_t)n * (g1 ? 192 : 384) / (compact ? 2 : 1);
   const size_t wsb = ozk_fixed_batch_msm_workspace_bytes(outerc, ws, n, bn_type);
-  DevBuf d;
-  OZK_HIP(hipStreamCreateWithFlags(&d.st, hipStreamNonBlocking));
-  const size_t a0 = 256, a1 = a0 + ((sc_bytes + 255) & ~(size_t)255), a2 = a1 + ((out_bytes + 255) & ~(size_t)255);
-  OZK_HIP(hipMalloc((void**)&d.p, a2 + wsb + 256));
-  OZK_HIP(hipMemcpyAsync(d.p, base, base_bytes, hipMemcpyHostToDevice, d.st));
-  OZK_HIP(hipMemcpyAsync(d.p + a0, scalars, sc_bytes, hipMemcpyHostToDevice, d.st));
-  rc = compact ? ozk_fixed_batch_msm_compact_dev(outerc, ws, n, d.p, d.p + a0, bn_type, d.p + a1, d.p + a2, wsb, d.st)
-               : ozk_fixed_batch_msm_dev(outerc, ws, n, d.p, d.p + a0, bn_type, d.p + a1, d.p + a2, wsb, d.st);
+  CtxGuard g;
+  if ((rc = ctx_acquire(task_id, &g.c))) return rc;
+  HostCtx* c = g.c;
+  const size_t a0 = 256, a1 = a0 + pad256(sc_bytes), a2 = a1 + pad256(out_bytes);
+  if ((rc = ctx_reserve(c, a2 + wsb + 256))) return rc;
+  uint8_t* d = c->arena;
+  hipStream_t st = c->st[0];
+  OZK_HIP(hipMemcpyAsync(d, base, base_bytes, hipMemcpyHostToDevice, st));
+  OZK_HIP(hipStreamSynchronize(st));   // `base` is the caller's (pageable) memory
+  if ((rc = staged_h2d(c, d + a0, scalars, sc_bytes, st))) return rc;
+  rc = compact ? ozk_fixed_batch_msm_compact_dev(outerc, ws, n, d, d + a0, bn_type, d + a1, d + a2, wsb, st)
+               : ozk_fixed_batch_msm_dev(outerc, ws, n, d, d + a0, bn_type, d + a1, d + a2, wsb, st);
   if (rc) return rc;
-  OZK_HIP(hipMemcpyAsync(out, d.p + a1, out_bytes, hipMemcpyDeviceToHost, d.st));
-  OZK_HIP(hipStreamSynchronize(d.st));
-  return OZK_OK;
+  return staged_d2h(c, out, d + a1, out_bytes, st);
 }
 
 int ozk_fixed_batch_msm_host(int32_t outerc, int32_t ws, int32_t out_len, int32_t inner_len, int32_t n,
@@ -506,26 +497,27 @@ int ozk_fixed_double_batch_msm_host(int32_t outerc1, int32_t ws1, int32_t outerc
   int rc = fb_check_args(outerc1, ws1, n);
   if (rc) return rc;
   if ((rc = fb_check_args(outerc2, ws2, n))) return rc;
-  if ((rc = select_device(task_id))) return rc;
   // per element G1 (3 x 64 BE) || G2 (6 x 64 BE) = 576 B  (FixedBaseMSM.cu:1479-1482)
   const size_t sc_bytes = (size_t)n * 32, out_bytes = (size_t)n * 576;
   const size_t w1 = fb_layout<G1Cfg>(outerc1, ws1, n, nullptr, 0).bytes;
   const size_t w2 = fb_layout<G2Cfg>(outerc2, ws2, n, nullptr, 0).bytes;
   const size_t wsb = w1 > w2 ? w1 : w2;
-  DevBuf d;
-  OZK_HIP(hipStreamCreateWithFlags(&d.st, hipStreamNonBlocking));
-  const size_t a0 = 512, a1 = a0 + ((sc_bytes + 255) & ~(size_t)255), a2 = a1 + ((out_bytes + 255) & ~(size_t)255);
-  OZK_HIP(hipMalloc((void**)&d.p, a2 + wsb + 256));
-  OZK_HIP(hipMemcpyAsync(d.p, base_g1, 96, hipMemcpyHostToDevice, d.st));
-  OZK_HIP(hipMemcpyAsync(d.p + 256, base_g2, 192, hipMemcpyHostToDevice, d.st));
-  OZK_HIP(hipMemcpyAsync(d.p + a0, scalars, sc_bytes, hipMemcpyHostToDevice, d.st));
-  rc = fixed_batch_dev<G1Cfg>(outerc1, ws1, n, d.p, d.p + a0, d.p + a1, 144, d.p + a2, wsb, d.st);
+  CtxGuard g;
+  if ((rc = ctx_acquire(task_id, &g.c))) return rc;
+  HostCtx* c = g.c;
+  const size_t a0 = 512, a1 = a0 + pad256(sc_bytes), a2 = a1 + pad256(out_bytes);
+  if ((rc = ctx_reserve(c, a2 + wsb + 256))) return rc;
+  uint8_t* d = c->arena;
+  hipStream_t st = c->st[0];
+  OZK_HIP(hipMemcpyAsync(d, base_g1, 96, hipMemcpyHostToDevice, st));
+  OZK_HIP(hipMemcpyAsync(d + 256, base_g2, 192, hipMemcpyHostToDevice, st));
+  OZK_HIP(hipStreamSynchronize(st));
+  if ((rc = staged_h2d(c, d + a0, scalars, sc_bytes, st))) return rc;
+  rc = fixed_batch_dev<G1Cfg>(outerc1, ws1, n, d, d + a0, d + a1, 144, d + a2, wsb, st);
   if (rc) return rc;
-  rc = fixed_batch_dev<G2Cfg>(outerc2, ws2, n, d.p + 256, d.p + a0, d.p + a1 + 192, 144, d.p + a2, wsb, d.st);
+  rc = fixed_batch_dev<G2Cfg>(outerc2, ws2, n, d + 256, d + a0, d + a1 + 192, 144, d + a2, wsb, st);
   if (rc) return rc;
-  OZK_HIP(hipMemcpyAsync(out, d.p + a1, out_bytes, hipMemcpyDeviceToHost, d.st));
-  OZK_HIP(hipStreamSynchronize(d.st));
-  return OZK_OK;
+  return staged_d2h(c, out, d + a1, out_bytes, st);
 }
 
 int ozk_field_batch_mul_dev(const void* d_in, int32_t n, void* d_out, void* stream) {
@@ -539,19 +531,18 @@ int ozk_field_batch_mul_dev(const void* d_in, int32_t n, void* d_out, void* stre
 int ozk_field_batch_mul_host(const uint8_t* in, int32_t n, int32_t task_id, uint8_t* out) {
   if (!in || !out) return fail(OZK_E_INVALID, "null pointer argument");
   if (n <= 0 || n > (1 << 24)) return fail(OZK_E_INVALID, "batch_size %d out of range", n);
-  int rc = select_device(task_id);
-  if (rc) return rc;
   const size_t in_bytes = (size_t)(n + 1) * 32, out_bytes = (size_t)n * 64;
-  DevBuf d;
-  OZK_HIP(hipStreamCreateWithFlags(&d.st, hipStreamNonBlocking));
-  const size_t a1 = (in_bytes + 255) & ~(size_t)255;
-  OZK_HIP(hipMalloc((void**)&d.p, a1 + out_bytes + 256));
-  OZK_HIP(hipMemcpyAsync(d.p, in, in_bytes, hipMemcpyHostToDevice, d.st));
-  rc = ozk_field_batch_mul_dev(d.p, n, d.p + a1, d.st);
+  CtxGuard g;
+  int rc = ctx_acquire(task_id, &g.c);
   if (rc) return rc;
-  OZK_HIP(hipMemcpyAsync(out, d.p + a1, out_bytes, hipMemcpyDeviceToHost, d.st));
-  OZK_HIP(hipStreamSynchronize(d.st));
-  return OZK_OK;
+  HostCtx* c = g.c;
+  const size_t a1 = pad256(in_bytes);
+  if ((rc = ctx_reserve(c, a1 + out_bytes + 256))) return rc;
+  uint8_t* d = c->arena;
+  hipStream_t st = c->st[0];
+  if ((rc = staged_h2d(c, d, in, in_bytes, st))) return rc;
+  if ((rc = ozk_field_batch_mul_dev(d, n, d + a1, st))) return rc;
+  return staged_d2h(c, out, d + a1, out_bytes, st);
 }
 
 }  // extern "C"

@@ -217,46 +217,33 @@ int ozk_var_double_msm_host(const uint8_t* bases_g1, const uint8_t* bases_g2, co
   // already runs on its own stream; the G1 tail then overlaps the G2 head.
   if (!bases_g1 || !bases_g2 || !scalars || !out) return fail(OZK_E_INVALID, "null pointer argument");
   if (n <= 0 || n > (1 << 24)) return fail(OZK_E_INVALID, "batch_size %d out of range [1, 2^24]", n);
-  int rc = select_device(task_id);
+  CtxGuard g;
+  int rc = ctx_acquire(task_id, &g.c);
   if (rc) return rc;
-  auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  HostCtx* c = g.c;
   const size_t b1 = (size_t)n * 96, b2 = (size_t)n * 192, sc = (size_t)n * 32;
   const size_t w1 = var_msm_ws_bytes<G1Cfg>(n), w2 = var_msm_ws_bytes<G2Cfg>(n);
-  uint8_t* d = nullptr;
-  hipStream_t s1 = nullptr, s2 = nullptr;
-  hipEvent_t e_sc = nullptr;
-  hipError_t e = hipMalloc((void**)&d, pad(b1) + pad(b2) + pad(sc) + 1024 + pad(w1) + pad(w2) + 1024);
-  if (e != hipSuccess) return fail(OZK_E_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
-  uint8_t* d_b1 = d;
-  uint8_t* d_b2 = d_b1 + pad(b1);
-  uint8_t* d_sc = d_b2 + pad(b2);
-  uint8_t* d_out = d_sc + pad(sc);
+  if ((rc = ctx_reserve(c, pad256(b1) + pad256(b2) + pad256(sc) + 1024 + pad256(w1) + pad256(w2) + 1024))) return rc;
+  uint8_t* d_b1 = c->arena;
+  uint8_t* d_b2 = d_b1 + pad256(b1);
+  uint8_t* d_sc = d_b2 + pad256(b2);
+  uint8_t* d_out = d_sc + pad256(sc);
   uint8_t* d_w1 = d_out + 1024;
-  uint8_t* d_w2 = d_w1 + pad(w1);
-  rc = OZK_OK;
-  do {
-    if ((e = hipStreamCreateWithFlags(&s1, hipStreamNonBlocking)) != hipSuccess) break;
-    if ((e = hipStreamCreateWithFlags(&s2, hipStreamNonBlocking)) != hipSuccess) break;
-    if ((e = hipEventCreateWithFlags(&e_sc, hipEventDisableTiming)) != hipSuccess) break;
-    if ((e = hipMemcpyAsync(d_sc, scalars, sc, hipMemcpyHostToDevice, s2)) != hipSuccess) break;
-    if ((e = hipEventRecord(e_sc, s2)) != hipSuccess) break;
-    if ((e = hipMemcpyAsync(d_b1, bases_g1, b1, hipMemcpyHostToDevice, s1)) != hipSuccess) break;
-    if ((e = hipStreamWaitEvent(s1, e_sc, 0)) != hipSuccess) break;
-    if ((rc = var_msm_dev<G1Cfg>(d_b1, d_sc, n, d_out, d_w1, w1, s1))) break;
-    if ((e = hipMemcpyAsync(out, d_out, 192, hipMemcpyDeviceToHost, s1)) != hipSuccess) break;
-    if ((e = hipMemcpyAsync(d_b2, bases_g2, b2, hipMemcpyHostToDevice, s2)) != hipSuccess) break;
-    if ((rc = var_msm_dev<G2Cfg>(d_b2, d_sc, n, d_out + 256, d_w2, w2, s2))) break;
-    if ((e = hipMemcpyAsync(out + 192, d_out + 256, 384, hipMemcpyDeviceToHost, s2)) != hipSuccess) break;
-  } while (0);
-  hipError_t e1 = s1 ? hipStreamSynchronize(s1) : hipSuccess;
-  hipError_t e2 = s2 ? hipStreamSynchronize(s2) : hipSuccess;
-  if (e == hipSuccess) e = e1 != hipSuccess ? e1 : e2;
-  if (e_sc) hipEventDestroy(e_sc);
-  if (s1) hipStreamDestroy(s1);
-  if (s2) hipStreamDestroy(s2);
-  hipFree(d);
-  if (rc) return rc;
-  if (e != hipSuccess) return fail(OZK_E_NO_DEVICE, "HIP failure in var_double_msm_host: %s", hipGetErrorString(e));
+  uint8_t* d_w2 = d_w1 + pad256(w1);
+  hipStream_t s1 = c->st[0], s2 = c->st[1];
+  // scalars and G1 bases on s1, G1 MSM on s1; the G2 bases follow on s2 (the host thread staging them while
+  // the G1 MSM runs) and the G2 MSM waits only for the scalars
+  if ((rc = staged_h2d(c, d_sc, scalars, sc, s1))) return rc;
+  OZK_HIP(hipEventRecord(c->ev[0], s1));
+  if ((rc = staged_h2d(c, d_b1, bases_g1, b1, s1))) return rc;
+  if ((rc = var_msm_dev<G1Cfg>(d_b1, d_sc, n, d_out, d_w1, w1, s1))) return rc;
+  OZK_HIP(hipStreamWaitEvent(s2, c->ev[0], 0));
+  if ((rc = staged_h2d(c, d_b2, bases_g2, b2, s2))) return rc;
+  if ((rc = var_msm_dev<G2Cfg>(d_b2, d_sc, n, d_out + 256, d_w2, w2, s2))) return rc;
+  OZK_HIP(hipMemcpyAsync(out, d_out, 192, hipMemcpyDeviceToHost, s1));
+  OZK_HIP(hipMemcpyAsync(out + 192, d_out + 256, 384, hipMemcpyDeviceToHost, s2));
+  OZK_HIP(hipStreamSynchronize(s1));
+  OZK_HIP(hipStreamSynchronize(s2));
   return OZK_OK;
 }
 

@@ -11,7 +11,7 @@
 #define OZK_WITH_G2 1
 #endif
 #include "msm_var.cuh"
-#include "ozk_common.h"
+#include "host_ctx.h"
 #include "fq2.cuh"
 
 namespace ozk {
@@ -470,42 +470,31 @@ size_t var_msm_ws_bytes(int n) {
   return var_msm_head_ws_bytes<CV>(n) + var_msm_tail_bytes<CV>(n);
 }
 
-// host-buffer variant: H2D, run, D2H.  Buffers are per call (re-entrant; callers are
-// concurrent Spark task threads in the reference, SURVEY.md §8b "Threading").
+// host-buffer variant (what the JNI native calls): staged upload, run, download, all on a cached context
+// (host_ctx.h) — no allocation, stream creation or pageable copy per call.  Re-entrant: concurrent callers
+// (Spark task threads in the reference, SURVEY.md §8b "Threading") each take their own context.
+// The scalars go up first so that the digit extraction and the first half of the sort input are ready while
+// the bases (3/4 of the bytes) are still on their way; the MSM itself needs everything.
 template <class CV>
 int var_msm_host(const uint8_t* bases, const uint8_t* scalars, int n, int task_id, uint8_t* out) {
   using IO = CurveIO<CV>;
-  int rc = select_device(task_id);
+  CtxGuard g;
+  int rc = ctx_acquire(task_id, &g.c);
   if (rc) return rc;
+  HostCtx* c = g.c;
   const size_t base_bytes = (size_t)n * IO::WIRE_JAC_WORDS * 4, sc_bytes = (size_t)n * 32;
   const size_t out_bytes = (size_t)IO::WIRE_JAC_WORDS * 8;
   const size_t ws_bytes = var_msm_ws_bytes<CV>(n);
-  uint8_t* d = nullptr;
-  hipStream_t st = nullptr;
-  OZK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-  hipError_t e = hipMalloc((void**)&d, base_bytes + sc_bytes + out_bytes + ws_bytes + 1024);
-  if (e != hipSuccess) {
-    hipStreamDestroy(st);
-    return fail(OZK_E_NOMEM, "hipMalloc(%zu) failed: %s", base_bytes + sc_bytes + ws_bytes, hipGetErrorString(e));
-  }
-  uint8_t* d_bases = d;
-  uint8_t* d_sc = d_bases + ((base_bytes + 255) & ~(size_t)255);
-  uint8_t* d_out = d_sc + ((sc_bytes + 255) & ~(size_t)255);
-  uint8_t* d_ws = d_out + 256 * ((out_bytes + 255) / 256);
-  rc = OZK_OK;
-  do {
-    if ((e = hipMemcpyAsync(d_bases, bases, base_bytes, hipMemcpyHostToDevice, st)) != hipSuccess) break;
-    if ((e = hipMemcpyAsync(d_sc, scalars, sc_bytes, hipMemcpyHostToDevice, st)) != hipSuccess) break;
-    rc = var_msm_dev<CV>(d_bases, d_sc, n, d_out, d_ws, ws_bytes, st);
-    if (rc) break;
-    if ((e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, st)) != hipSuccess) break;
-    e = hipStreamSynchronize(st);
-  } while (0);
-  hipFree(d);
-  hipStreamDestroy(st);
-  if (rc) return rc;
-  if (e != hipSuccess) return fail(OZK_E_NO_DEVICE, "HIP failure in var_msm_host: %s", hipGetErrorString(e));
-  return OZK_OK;
+  if ((rc = ctx_reserve(c, pad256(base_bytes) + pad256(sc_bytes) + 1024 + ws_bytes + 1024))) return rc;
+  uint8_t* d_bases = c->arena;
+  uint8_t* d_sc = d_bases + pad256(base_bytes);
+  uint8_t* d_out = d_sc + pad256(sc_bytes);
+  uint8_t* d_ws = d_out + 1024;
+  hipStream_t st = c->st[0];
+  if ((rc = staged_h2d(c, d_sc, scalars, sc_bytes, st))) return rc;
+  if ((rc = staged_h2d(c, d_bases, bases, base_bytes, st))) return rc;
+  if ((rc = var_msm_dev<CV>(d_bases, d_sc, n, d_out, d_ws, ws_bytes, st))) return rc;
+  return staged_d2h(c, out, d_out, out_bytes, st);
 }
 
 // ---- prepared bases: the affine Montgomery records (GLV: both halves) of a base
@@ -559,8 +548,13 @@ int bases_create(const uint8_t* bases, int n, int type, int task_id, BasesHandle
   if (e == hipSuccess) e = hipMalloc((void**)&h->d_ws, h->ws_bytes);
   if (e == hipSuccess) e = hipMalloc((void**)&d_wire, wire);
   rc = OZK_OK;
-  if (e == hipSuccess) e = hipMemcpyAsync(d_wire, bases, wire, hipMemcpyHostToDevice, h->st);
-  if (e == hipSuccess) rc = var_msm_prepare<CV>(d_wire, n, h->d_prepared, pb, h->st);
+  if (e == hipSuccess) {
+    CtxGuard g;  // only for its pinned staging ring
+    rc = ctx_acquire(task_id, &g.c);
+    if (!rc) rc = staged_h2d(g.c, d_wire, bases, wire, h->st);
+    if (!rc) e = hipStreamSynchronize(h->st);
+  }
+  if (e == hipSuccess && !rc) rc = var_msm_prepare<CV>(d_wire, n, h->d_prepared, pb, h->st);
   if (e == hipSuccess && !rc) e = hipStreamSynchronize(h->st);
   if (d_wire) hipFree(d_wire);
   if (e != hipSuccess || rc) {
@@ -590,7 +584,13 @@ int bases_msm(BasesHandle* h, const uint8_t* scalars, uint8_t* out) {
   hipError_t e = hipSetDevice(h->device);
   do {
     if (e != hipSuccess) break;
-    if ((e = hipMemcpyAsync(h->d_scalars, scalars, (size_t)h->n * 32, hipMemcpyHostToDevice, h->st)) != hipSuccess) break;
+    {
+      CtxGuard g;  // pinned staging ring for the scalars
+      rc = ctx_acquire(h->device, &g.c);
+      if (!rc) rc = staged_h2d(g.c, h->d_scalars, scalars, (size_t)h->n * 32, h->st);
+      if (!rc) e = hipStreamSynchronize(h->st);   // the ring goes back to the pool with nothing in flight
+    }
+    if (rc || e != hipSuccess) break;
     rc = var_msm_dev<CV>(nullptr, h->d_scalars, h->n, h->d_out, h->d_ws, h->ws_bytes, h->st, h->d_prepared);
     if (rc) break;
     if ((e = hipMemcpyAsync(out, h->d_out, out_bytes, hipMemcpyDeviceToHost, h->st)) != hipSuccess) break;

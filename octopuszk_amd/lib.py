@@ -56,6 +56,7 @@ _SIGS = {
     "ozk_fft_compact_host": (ctypes.c_int, [vp, i32, vp, i32, vp]),
     "ozk_fft_compact_dev": (ctypes.c_int, [vp, i32, vp, vp, vp, sz, vp]),
     "ozk_tuning_reload": (ctypes.c_int, []),
+    "ozk_host_cache_release": (ctypes.c_int, []),
     "ozk_bases_type": (ctypes.c_int, [vp]),
     "ozk_fft_host": (ctypes.c_int, [vp, i32, vp, i32, vp]),
     "ozk_fft_workspace_bytes": (sz, [i32]),

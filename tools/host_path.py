@@ -1,0 +1,143 @@
+#!/usr/bin/env python3
+"""Wall time of the JNI-shaped (`*_host`) entry points as a Java caller sees them: inputs in PAGEABLE host
+memory that the runtime has never seen (a fresh buffer per call), result back in host memory.  Prints, per
+entry point, the first call (cold: context creation, arena growth) and min / median of the following ones, next
+to the bytes moved and the device-resident time of the same operation.  Output is committed under profiles/."""
+import ctypes
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from octopuszk_amd import device as dev  # noqa: E402
+from octopuszk_amd import lib as ozk  # noqa: E402
+from oracle import bn254 as o  # noqa: E402
+
+L = ozk.load()
+
+
+def vp(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def scalars(n, seed):
+    b = np.random.default_rng(seed).integers(0, 256, size=(n, 32), dtype=np.uint8)
+    b[:, 31] &= 0x1F
+    return b
+
+
+def fresh(a):
+    """a new pageable copy (what GetPrimitiveArrayCritical hands over changes from call to call)"""
+    return np.array(a, copy=True)
+
+
+def run(name, fn, make_inputs, reps, moved_mib, dev_ms=None):
+    times = []
+    for _ in range(reps + 1):
+        args = make_inputs()
+        t0 = time.perf_counter()
+        fn(*args)
+        times.append((time.perf_counter() - t0) * 1e3)
+    warm = sorted(times[1:])
+    extra = "" if dev_ms is None else "  | device-resident %.2f ms" % dev_ms
+    print("%-46s first %8.2f ms | min %7.2f  median %7.2f ms | %5.0f MiB over PCIe%s   all: %s"
+          % (name, times[0], warm[0], warm[len(warm) // 2], moved_mib, extra, " ".join("%.1f" % t for t in times[1:])), flush=True)
+
+
+def main():
+    logn = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    n = 1 << logn
+    print("device:", torch.cuda.get_device_name(0), " n = 2^%d" % logn, flush=True)
+    g1 = bytes(dev.gen_g1_bases(n, seed=2).cpu().numpy())
+    g1 = np.frombuffer(g1, dtype=np.uint8)
+    sc = scalars(n, 1)
+    out = np.zeros(576, dtype=np.uint8)
+    # device-resident reference
+    d_b, d_s = torch.from_numpy(g1.copy()).cuda(), torch.from_numpy(sc.reshape(-1)).cuda()
+    ws = dev.VarMsmWorkspace(n, 1)
+    ws.run(d_b, d_s)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        ws.run(d_b, d_s)
+    torch.cuda.synchronize()
+    dev_ms = (time.perf_counter() - t0) / 5 * 1e3
+    want = bytes(ws.out.cpu().numpy())
+
+    def var_g1(b, s):
+        ozk.check(L.ozk_var_msm_host(vp(b), vp(s), n, 1, 0, vp(out)))
+        assert bytes(out[:192]) == want
+
+    run("ozk_var_msm_host G1", var_g1, lambda: (fresh(g1), fresh(sc)), 6, n * 128 / 2**20, dev_ms)
+    # prepared bases: scalars only
+    h = ctypes.c_void_p()
+    ozk.check(L.ozk_bases_create_host(vp(g1), n, 1, 0, ctypes.byref(h)))
+
+    def var_prep(s):
+        ozk.check(L.ozk_var_msm_bases_host(h, vp(s), n, vp(out)))
+        assert bytes(out[:192]) == want
+
+    run("ozk_var_msm_bases_host G1 (prepared)", var_prep, lambda: (fresh(sc),), 6, n * 32 / 2**20, dev_ms)
+    ozk.check(L.ozk_bases_destroy(h))
+    # double MSM at n / 4 (the Java chunk is 2^21; G2 bases 192 B each)
+    m = n // 4
+    ks = scalars(m, 9)
+    ks[:, 8:] = 0
+    st = int(torch.cuda.current_stream().cuda_stream)
+    base2 = torch.from_numpy(np.frombuffer(o.g2_to_wire(o.G2.one), dtype=np.uint8).copy()).cuda()
+    g2d = torch.empty(m * 192, dtype=torch.uint8, device="cuda")
+    wsb = int(L.ozk_fixed_batch_msm_workspace_bytes(16, 16, m, 2))
+    wsf = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    ozk.check(L.ozk_fixed_batch_msm_compact_dev(16, 16, m, int(base2.data_ptr()), int(torch.from_numpy(ks.reshape(-1)).cuda().data_ptr()),
+                                                2, int(g2d.data_ptr()), int(wsf.data_ptr()), wsb, st))
+    torch.cuda.synchronize()
+    g2 = g2d.cpu().numpy()
+    del wsf, g2d
+
+    def dbl(b1, b2, s):
+        ozk.check(L.ozk_var_double_msm_host(vp(b1), vp(b2), vp(s), m, 0, vp(out)))
+
+    run("ozk_var_double_msm_host n/4", dbl, lambda: (fresh(g1[:m * 96]), fresh(g2), fresh(sc[:m])), 4, m * 320 / 2**20)
+    # fixed base G1 / G2, window 17
+    for bn, name in ((1, "G1"), (2, "G2")):
+        per = 192 if bn == 1 else 384
+        C = o.G1 if bn == 1 else o.G2
+        bw = np.frombuffer(o.g1_to_wire(C.one) if bn == 1 else o.g2_to_wire(C.one), dtype=np.uint8)
+        fout = np.zeros(n * per, dtype=np.uint8)
+
+        def fb(s):
+            ozk.check(L.ozk_fixed_batch_msm_host(15, 17, 15, 1 << 17, n, 254, vp(bw), vp(s), bn, 0, vp(fout)))
+
+        run("ozk_fixed_batch_msm_host %s w=17" % name, fb, lambda: (fresh(sc),), 4, n * (32 + per) / 2**20)
+        cout = np.zeros(n * per // 2, dtype=np.uint8)
+
+        def fbc(s):
+            ozk.check(L.ozk_fixed_batch_msm_compact_host(15, 17, n, vp(bw), vp(s), bn, 0, vp(cout)))
+
+        run("ozk_fixed_batch_msm_compact_host %s" % name, fbc, lambda: (fresh(sc),), 4, n * (32 + per // 2) / 2**20)
+        del fout, cout
+    # FFT 4n (2^22 at the default), reference format and compact
+    nf = 4 * n
+    a = scalars(nf, 3)
+    om = np.frombuffer(o.to_le32(o.fr_root_of_unity(nf)), dtype=np.uint8)
+    f64, f32 = np.zeros(nf * 64, dtype=np.uint8), np.zeros(nf * 32, dtype=np.uint8)
+    run("ozk_fft_host n=2^%d" % (logn + 2), lambda x: ozk.check(L.ozk_fft_host(vp(x), nf, vp(om), 0, vp(f64))),
+        lambda: (fresh(a),), 4, nf * 96 / 2**20)
+    run("ozk_fft_compact_host n=2^%d" % (logn + 2), lambda x: ozk.check(L.ozk_fft_compact_host(vp(x), nf, vp(om), 0, vp(f32))),
+        lambda: (fresh(a),), 4, nf * 64 / 2**20)
+    # witness map at 2n
+    mq = 2 * n
+    ev = [scalars(mq, 20 + k) for k in range(3)]
+    gq = np.frombuffer(o.to_le32(o.FR_MULT_GEN), dtype=np.uint8)
+    omq = np.frombuffer(o.to_le32(o.fr_root_of_unity(mq)), dtype=np.uint8)
+    hq = np.zeros((mq + 1) * 32, dtype=np.uint8)
+    run("ozk_qap_witness_host m=2^%d" % (logn + 1),
+        lambda x, y, z: ozk.check(L.ozk_qap_witness_host(vp(x), vp(y), vp(z), mq, vp(omq), vp(gq), 0, vp(hq))),
+        lambda: tuple(fresh(e) for e in ev), 4, mq * 128 / 2**20)
+
+
+if __name__ == "__main__":
+    main()
