@@ -69,6 +69,18 @@ int ozk_var_msm_host(const uint8_t* bases, const uint8_t* scalars, int32_t n, in
 int ozk_var_double_msm_host(const uint8_t* bases_g1, const uint8_t* bases_g2,
                             const uint8_t* scalars, int32_t n, int32_t task_id, uint8_t* out);
 
+/* The same MSM spread over several GPUs from ONE call (no counterpart in the reference, whose native uses the
+ * one device `taskID % count` selects, algebra_msm_VariableBaseMSM.cu:1249-1257; its multi-GPU form is one
+ * Spark partition per device, VariableBaseMSM.java:775-786): the index range is cut into `shards` contiguous
+ * slices (<= 0: one per visible device), slice i runs on device i % count from its own host thread, the
+ * partial results are added on device 0.  Same bytes out as ozk_var_msm_host.  ozk_var_msm_auto_host is what
+ * the JNI shim calls: sharded when several devices are visible and n >= OZK_SHARD_MIN_N (2^21), else
+ * ozk_var_msm_host. */
+int ozk_var_msm_sharded_host(const uint8_t* bases, const uint8_t* scalars, int32_t n, int32_t type, int32_t shards,
+                             uint8_t* out);
+int ozk_var_msm_auto_host(const uint8_t* bases, const uint8_t* scalars, int32_t n, int32_t type, int32_t task_id,
+                          uint8_t* out);
+
 /* Device-resident variants.  `workspace` must hold ozk_var_msm_workspace_bytes(n, type)
  * bytes; all pointers are device pointers; `stream` is a hipStream_t (NULL = default). */
 size_t ozk_var_msm_workspace_bytes(int32_t n, int32_t type);

@@ -12,7 +12,8 @@ JNIEXPORT jbyteArray JNICALL Java_algebra_msm_VariableBaseMSM_variableBaseSerial
   jbyte* s = ozk_borrow(env, scalars, 32LL * batch_size, "scalars");
   if (!s) { ozk_release(env, bases, b); return NULL; }
   uint8_t out[384];
-  const int rc = ozk_var_msm_host((const uint8_t*)b, (const uint8_t*)s, batch_size, type, taskID, out);
+  /* one GPU (taskID % count), or all visible ones for a large call (include/ozk.h) */
+  const int rc = ozk_var_msm_auto_host((const uint8_t*)b, (const uint8_t*)s, batch_size, type, taskID, out);
   ozk_release(env, scalars, s);
   ozk_release(env, bases, b);
   if (rc) return ozk_throw_last(env, "variableBaseSerialMSMNativeHelper", rc);

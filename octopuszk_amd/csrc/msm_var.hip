@@ -4,6 +4,10 @@
 // the two JNI natives of algebra.msm.VariableBaseMSM (.cu:1614-1788).
 #include "msm_var_driver.cuh"
 
+#include <string>
+#include <thread>
+#include <vector>
+
 OZK_G2_DRIVER_INSTANCES(extern)
 
 using namespace ozk;
@@ -245,6 +249,69 @@ int ozk_var_double_msm_host(const uint8_t* bases_g1, const uint8_t* bases_g2, co
   OZK_HIP(hipStreamSynchronize(s1));
   OZK_HIP(hipStreamSynchronize(s2));
   return OZK_OK;
+}
+
+// In-process multi-GPU MSM for ONE caller (a serial Java prover calls the native once, with taskID 0: the
+// reference then uses one GPU, algebra_msm_VariableBaseMSM.cu:1249-1257; its multi-GPU form needs Spark
+// partitions, VariableBaseMSM.java:775-786).  The (scalar, base) index range is cut into `shards` contiguous
+// slices (shards <= 0: one per visible device); slice i runs the whole single-GPU pipeline on device
+// i % device_count from its own host thread and context; the 192 / 384-byte partials come back to the host
+// and are added on device 0 (the reduce(GroupT::add) of VariableBaseMSM.java:783) — the exchange is
+// shards x 192 B, so there is nothing for a collective library to do here (the one-process-per-GPU form,
+// octopuszk_amd/distributed.py, all-gathers the same partials over RCCL).
+static int var_msm_shard(const uint8_t* bases, const uint8_t* scalars, int n, int type, int task_id, uint8_t* out) {
+  return type == OZK_G1 ? var_msm_host<G1Cfg>(bases, scalars, n, task_id, out)
+                        : var_msm_host<G2Cfg>(bases, scalars, n, task_id, out);
+}
+
+int ozk_var_msm_sharded_host(const uint8_t* bases, const uint8_t* scalars, int32_t n, int32_t type, int32_t shards,
+                             uint8_t* out) {
+  if (!bases || !scalars || !out) return fail(OZK_E_INVALID, "null pointer argument");
+  if (n <= 0) return fail(OZK_E_INVALID, "batch_size %d out of range", n);
+  const int ndev = ozk_device_count();
+  if (ndev <= 0) return fail(OZK_E_NO_DEVICE, "no HIP device available; this library has no CPU path");
+  int k = shards > 0 ? shards : ndev;
+  if (k > n) k = n;
+  if (k > 64) k = 64;
+  const size_t pt = type == OZK_G1 ? 96 : 192, ob = type == OZK_G1 ? 192 : 384;
+  if (k == 1) return var_msm_shard(bases, scalars, n, type, 0, out);
+  std::vector<uint8_t> partial((size_t)k * ob);
+  std::vector<int> rcs(k, OZK_OK);
+  std::vector<std::string> msgs(k);
+  std::vector<std::thread> th;
+  const int base_n = n / k, rem = n % k;
+  for (int i = 0; i < k; i++) {
+    const size_t lo = (size_t)i * base_n + (size_t)(i < rem ? i : rem);
+    const int cnt = base_n + (i < rem ? 1 : 0);
+    th.emplace_back([&, i, lo, cnt] {
+      rcs[i] = var_msm_shard(bases + lo * pt, scalars + lo * 32, cnt, type, i, partial.data() + (size_t)i * ob);
+      if (rcs[i]) msgs[i] = err_buf();   // the message lives in that thread's buffer
+    });
+  }
+  for (auto& t : th) t.join();
+  for (int i = 0; i < k; i++)
+    if (rcs[i]) return fail(rcs[i], "shard %d of %d: %s", i, k, msgs[i].c_str());
+  // sum of the partials on device 0
+  CtxGuard g;
+  int rc = ctx_acquire(0, &g.c);
+  if (rc) return rc;
+  HostCtx* c = g.c;
+  if ((rc = ctx_reserve(c, pad256(partial.size()) + 1024))) return rc;
+  OZK_HIP(hipMemcpyAsync(c->arena, partial.data(), partial.size(), hipMemcpyHostToDevice, c->st[0]));
+  uint8_t* d_out = c->arena + pad256(partial.size());
+  if ((rc = ozk_points_sum_dev(c->arena, k, type, d_out, c->st[0]))) return rc;
+  OZK_HIP(hipMemcpyAsync(out, d_out, ob, hipMemcpyDeviceToHost, c->st[0]));
+  OZK_HIP(hipStreamSynchronize(c->st[0]));
+  return OZK_OK;
+}
+
+// What the JNI native calls: one GPU (taskID % count, as the reference) unless several are visible and the
+// call is large enough to be worth spreading (OZK_SHARD_MIN_N pairs, default 2^21; OZK_SHARD=0 disables).
+int ozk_var_msm_auto_host(const uint8_t* bases, const uint8_t* scalars, int32_t n, int32_t type, int32_t task_id,
+                          uint8_t* out) {
+  if (env_int("OZK_SHARD", 1) && n >= env_int("OZK_SHARD_MIN_N", 1 << 21) && ozk_device_count() > 1)
+    return ozk_var_msm_sharded_host(bases, scalars, n, type, env_int("OZK_SHARD_COUNT", 0), out);
+  return ozk_var_msm_host(bases, scalars, n, type, task_id, out);
 }
 
 int ozk_points_sum_dev(const void* d_points, int32_t k, int32_t type, void* d_out, void* stream) {

@@ -19,6 +19,8 @@ _SIGS = {
     "ozk_device_count": (ctypes.c_int, []),
     "ozk_var_msm_host": (ctypes.c_int, [vp, vp, i32, i32, i32, vp]),
     "ozk_var_double_msm_host": (ctypes.c_int, [vp, vp, vp, i32, i32, vp]),
+    "ozk_var_msm_sharded_host": (ctypes.c_int, [vp, vp, i32, i32, i32, vp]),
+    "ozk_var_msm_auto_host": (ctypes.c_int, [vp, vp, i32, i32, i32, vp]),
     "ozk_var_msm_workspace_bytes": (sz, [i32, i32]),
     "ozk_var_msm_dev": (ctypes.c_int, [vp, vp, i32, i32, vp, vp, sz, vp]),
     "ozk_prof_enable": (ctypes.c_int, [ctypes.c_int]),

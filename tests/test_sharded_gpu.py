@@ -107,3 +107,33 @@ def test_bench_two_ranks_on_one_gpu_result_is_the_global_msm():
         acc += sum(k * int.from_bytes(s.tobytes(), "little") for k, s in zip(ks, sc))
     want = o.g1_out_le(o.G1.to_affine(o.G1.mul(o.G1.one, acc % o.R)))
     assert bytes.fromhex(d["config"]["result_hex"]) == want
+
+
+@pytest.mark.parametrize("type_,n,shards", [(1, 5001, 3), (1, 4, 8), (2, 301, 2), (1, 70000, 4)])
+def test_in_process_sharded_entry_equals_single_call(type_, n, shards):
+    """ozk_var_msm_sharded_host (what the JNI native routes large calls to when several GPUs are visible): the
+    slices run concurrently from their own host threads — here all on device 0 — and the summed result must be
+    the single-call bytes, which are the oracle's."""
+    import ctypes
+    from octopuszk_amd import lib
+    L = lib.load()
+    rng = np.random.default_rng(n + shards)
+    G = o.G1 if type_ == 1 else o.G2
+    to_wire = o.g1_to_wire if type_ == 1 else o.g2_to_wire
+    pts = [G.to_affine(G.mul(G.one, int(k))) for k in rng.integers(1, 1 << 62, size=16)]
+    pts[3] = G.zero
+    bw = np.frombuffer(b"".join(to_wire(pts[i % 16]) for i in range(n)), dtype=np.uint8)
+    sc = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    sc[:, 31] &= 0x1F
+    ob = 192 if type_ == 1 else 384
+    got, one = np.zeros(ob, dtype=np.uint8), np.zeros(ob, dtype=np.uint8)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    lib.check(L.ozk_var_msm_sharded_host(vp(bw), vp(sc), n, type_, shards, vp(got)))
+    lib.check(L.ozk_var_msm_host(vp(bw), vp(sc), n, type_, 0, vp(one)))
+    assert bytes(got) == bytes(one)
+    if n <= 6000:
+        scal = [int.from_bytes(sc[i].tobytes(), "little") for i in range(n)]
+        want = G.to_affine(o.pippenger_msm(G, scal, [pts[i % 16] for i in range(n)]))
+        assert bytes(got) == (o.g1_out_le(want) if type_ == 1 else o.g2_out_le(want))
+    elif type_ == 1:
+        assert bytes(got) == coracle.pippenger_g1(bw.tobytes(), sc.tobytes(), n)
