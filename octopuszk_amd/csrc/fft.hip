@@ -23,9 +23,13 @@
 namespace ozk {
 
 using FrP = FrParams;
-constexpr int FFT_TILE = 1024;   // elements per workgroup tile
+// Elements per workgroup tile: 2048 (72 KiB of LDS at 9 words each, two workgroups per CU) lets a pass do up
+// to 11 stages, so 2^22 is TWO passes over HBM instead of three (round 1: 1024-element tiles, 8 stages per
+// pass, 0.77 ms at 2^22 of which ~70 us per pass is the tile's trip through HBM).  512 threads per workgroup keep two
+// butterflies per thread and stage and four waves per SIMD.
+constexpr int FFT_TILE_BIG = 2048, FFT_TILE_SMALL = 1024;
 constexpr int FFT_THREADS = 256;
-constexpr int FFT_MAXK = 8;      // stages per pass
+constexpr int FFT_MAXK = 11;     // stages per pass (log2 of the biggest tile)
 constexpr int TW_LO = 2048;
 
 // ---- twiddle table -------------------------------------------------------
@@ -74,25 +78,25 @@ struct PassArgs {
   int K;            // stages in this pass
 };
 
-template <int B>
+template <int B, int TILE>
 __device__ __forceinline__ Fe<FrP, B> lds_load(const u32* lds, int e) {
   Fe<FrP, B> r;
 #pragma unroll
-  for (int i = 0; i < 9; i++) r.l[i] = lds[i * FFT_TILE + e];
+  for (int i = 0; i < 9; i++) r.l[i] = lds[i * TILE + e];
   return r;
 }
-template <int B>
+template <int TILE, int B>
 __device__ __forceinline__ void lds_store(u32* lds, int e, const Fe<FrP, B>& v) {
 #pragma unroll
-  for (int i = 0; i < 9; i++) lds[i * FFT_TILE + e] = v.l[i];
+  for (int i = 0; i < 9; i++) lds[i * TILE + e] = v.l[i];
 }
 
 // stage q (1-based inside the pass) with element bound BIN; recursion unrolls the K stages
-template <int Q, int BIN>
+template <int Q, int BIN, int TILE>
 __device__ __forceinline__ void fft_stages(u32* lds, const PassArgs& a, int T, int logT, long long u0) {
   if (Q > a.K) return;
-  const int M2T = FFT_TILE / 2;  // butterflies per stage in the tile
-  for (int b = threadIdx.x; b < M2T; b += FFT_THREADS) {
+  const int M2T = TILE / 2;  // butterflies per stage in the tile
+  for (int b = threadIdx.x; b < M2T; b += TILE / 4) {
     const int ul = b & (T - 1);
     const int r = b >> logT;
     const int low = r & ((1 << (Q - 1)) - 1);
@@ -105,28 +109,26 @@ __device__ __forceinline__ void fft_stages(u32* lds, const PassArgs& a, int T, i
     const long long ti = j << (a.logn - a.sbits - Q);
     const auto w = ElemTraits<Fe<FrP, 16>>::load(a.tw + (size_t)ti * 8);
     const int e0 = mid0 * T + ul, e1 = mid1 * T + ul;
-    const auto x = lds_load<BIN>(lds, e0);
-    const auto y = lds_load<BIN>(lds, e1);
+    const auto x = lds_load<BIN, TILE>(lds, e0);
+    const auto y = lds_load<BIN, TILE>(lds, e1);
     const auto t = mul(w, y);                       // plain product (w is Montgomery)
-    lds_store(lds, e0, Fe<FrP, BIN + 32>(add(x, t)));
-    lds_store(lds, e1, Fe<FrP, BIN + 32>(sub(x, t)));
+    lds_store<TILE>(lds, e0, Fe<FrP, BIN + 32>(add(x, t)));
+    lds_store<TILE>(lds, e1, Fe<FrP, BIN + 32>(sub(x, t)));
   }
   block_sync();
-  if constexpr (Q < FFT_MAXK) fft_stages<Q + 1, BIN + 32>(lds, a, T, logT, u0);
+  if constexpr ((1 << Q) < TILE) fft_stages<Q + 1, BIN + 32, TILE>(lds, a, T, logT, u0);
 }
 
-template <int BEND>
+template <int BEND, int TILE>
 __device__ __forceinline__ void fft_store_tile(u32* lds, const PassArgs& a, int T, int logT, long long u0,
                                                bool last) {
-  const int M = FFT_TILE >> logT;
-  (void)M;
-  for (int e = threadIdx.x; e < FFT_TILE; e += FFT_THREADS) {
+  for (int e = threadIdx.x; e < TILE; e += TILE / 4) {
     // consecutive lanes -> consecutive ul (contiguous addresses within a T-run)
     const int ul = e & (T - 1), mid = e >> logT;
     const long long u = u0 + ul;
     const long long hi = u >> a.sbits, lo = u & ((1ll << a.sbits) - 1);
     const long long i = (hi << (a.sbits + a.K)) | ((long long)mid << a.sbits) | lo;
-    const auto v = lds_load<BEND>(lds, mid * T + ul);
+    const auto v = lds_load<BEND, TILE>(lds, mid * T + ul);
     u32 o[8];
     if (last) {
       pack(canonical(v), o);
@@ -146,15 +148,15 @@ __device__ __forceinline__ void fft_store_tile(u32* lds, const PassArgs& a, int 
   }
 }
 
-template <bool FIRST>
-__global__ void __launch_bounds__(FFT_THREADS) k_fft_pass(PassArgs a, int last) {
-  extern __shared__ __attribute__((aligned(16))) u32 lds[];  // 9 * FFT_TILE words
+template <bool FIRST, int TILE>
+__global__ void __launch_bounds__(TILE / 4) k_fft_pass(PassArgs a, int last) {
+  extern __shared__ __attribute__((aligned(16))) u32 lds[];  // 9 * TILE words
   const int M = 1 << a.K;
-  const int T = FFT_TILE / M;
+  const int T = TILE / M;
   const int logT = 31 - __clz(T);
   const long long u0 = (long long)blockIdx.x * T;
   // load the tile: element (mid, ul) <- global index i (FIRST: bit-reversed source)
-  for (int e = threadIdx.x; e < FFT_TILE; e += FFT_THREADS) {
+  for (int e = threadIdx.x; e < TILE; e += TILE / 4) {
     const int ul = e & (T - 1), mid = e >> logT;
     const long long u = u0 + ul;
     const long long hi = u >> a.sbits, lo = u & ((1ll << a.sbits) - 1);
@@ -165,13 +167,14 @@ __global__ void __launch_bounds__(FFT_THREADS) k_fft_pass(PassArgs a, int last) 
     const uint4 v0 = sp[0], v1 = sp[1];
     const u32 w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
     // FIRST: arbitrary 256-bit wire value (bound 85); later passes: stored < 4p
-    lds_store(lds, mid * T + ul, unpack<FrP, 85>(w));
+    lds_store<TILE>(lds, mid * T + ul, unpack<FrP, 85>(w));
   }
   block_sync();
   constexpr int B0 = 96;  // >= 85 (any 256-bit input) and >= 64 (inter-pass storage)
-  fft_stages<1, B0>(lds, a, T, logT, u0);
-  // after K stages the bound is B0 + 32*K <= B0 + 32*FFT_MAXK
-  fft_store_tile<B0 + 32 * FFT_MAXK>(lds, a, T, logT, u0, last != 0);
+  fft_stages<1, B0, TILE>(lds, a, T, logT, u0);
+  // after K stages the bound is B0 + 32*K <= B0 + 32*log2(TILE)
+  constexpr int LOGT = TILE == 2048 ? 11 : (TILE == 1024 ? 10 : 9);
+  fft_store_tile<B0 + 32 * LOGT, TILE>(lds, a, T, logT, u0, last != 0);
 }
 
 // n == 1 or tiny n (< FFT_TILE): one workgroup, direct global-memory version of the same
@@ -254,20 +257,35 @@ static void fft_build_twiddles(const u32* d_omega, int n, u32* small, u32* tw, h
 static int fft_core(const u32* d_in, int n, const u32* tw, u32* d_out, int out_stride, u32* buf0, u32* buf1,
                     hipStream_t st) {
   const int logn = ilog2((uint32_t)n);
-  if (n < FFT_TILE) {
+  if (n < FFT_TILE_SMALL) {
     hipLaunchKernelGGL(k_fft_small, dim3(1), dim3(FFT_THREADS), 0, st, d_in, d_out, tw, n, logn, buf0, out_stride);
     OZK_HIP(hipGetLastError());
     return OZK_OK;
   }
-  // passes of up to FFT_MAXK stages; the tile needs 2^K <= FFT_TILE
+  // Passes of at most 8 stages (11 with the 2048-element tile), the stages spread evenly, the larger share
+  // first (the first pass reads bit-reversed and writes a contiguous tile whatever K is; a later pass with K
+  // stages touches HBM in runs of TILE / 2^K elements).  OZK_FFT_TILE = 512 | 1024 | 2048 selects the tile.
+  int tile = env_int("OZK_FFT_TILE", FFT_TILE_SMALL);
+  if (tile != 512 && tile != 1024 && tile != 2048) tile = FFT_TILE_SMALL;
+  if (tile > n) tile = FFT_TILE_SMALL;
+  const int maxk = tile == 2048 ? 11 : 8;
+  const int npass = (logn + maxk - 1) / maxk;
   int sbits = 0, cur = 0;
   u32* bufs[2] = {buf0, buf1};
   const u32* src = d_in;
-  bool first = true;
-  while (sbits < logn) {
-    int K = logn - sbits;
-    if (K > FFT_MAXK) K = FFT_MAXK;
-    const bool last = sbits + K == logn;
+  const size_t lds_bytes = (size_t)9 * tile * 4;
+  if (tile == 2048) {
+    static bool attr_set = false;  // (idempotent; a race only repeats it)
+    if (!attr_set) {
+      OZK_HIP(hipFuncSetAttribute((const void*)(k_fft_pass<true, 2048>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      OZK_HIP(hipFuncSetAttribute((const void*)(k_fft_pass<false, 2048>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      attr_set = true;
+    }
+  }
+  for (int pass = 0; pass < npass; pass++) {
+    const int left = logn - sbits, passes_left = npass - pass;
+    const int K = (left + passes_left - 1) / passes_left;
+    const bool last = pass == npass - 1;
     PassArgs a;
     a.in = src;
     a.out = last ? d_out : bufs[cur];
@@ -277,16 +295,23 @@ static int fft_core(const u32* d_in, int n, const u32* tw, u32* d_out, int out_s
     a.logn = logn;
     a.sbits = sbits;
     a.K = K;
-    const int tiles = n / FFT_TILE;
-    const size_t lds_bytes = (size_t)9 * FFT_TILE * 4;
-    if (first)
-      hipLaunchKernelGGL((k_fft_pass<true>), dim3(tiles), dim3(FFT_THREADS), lds_bytes, st, a, last ? 1 : 0);
-    else
-      hipLaunchKernelGGL((k_fft_pass<false>), dim3(tiles), dim3(FFT_THREADS), lds_bytes, st, a, last ? 1 : 0);
+    const int tiles = n / tile, li = last ? 1 : 0;
+#define OZK_FFT_LAUNCH(TL)                                                                                          \
+  if (pass == 0)                                                                                                    \
+    hipLaunchKernelGGL((k_fft_pass<true, TL>), dim3(tiles), dim3(TL / 4), lds_bytes, st, a, li);                    \
+  else                                                                                                              \
+    hipLaunchKernelGGL((k_fft_pass<false, TL>), dim3(tiles), dim3(TL / 4), lds_bytes, st, a, li);
+    if (tile == 2048) {
+      OZK_FFT_LAUNCH(2048)
+    } else if (tile == 512) {
+      OZK_FFT_LAUNCH(512)
+    } else {
+      OZK_FFT_LAUNCH(1024)
+    }
+#undef OZK_FFT_LAUNCH
     src = a.out;
     cur ^= 1;
     sbits += K;
-    first = false;
   }
   OZK_HIP(hipGetLastError());
   return OZK_OK;

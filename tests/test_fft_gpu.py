@@ -96,3 +96,28 @@ def test_fft_large_properties():
     for row in a:
         s += int.from_bytes(row.tobytes(), "little")
     assert val(fa[0]) == s % o.R
+
+
+@pytest.mark.parametrize("tile", [512, 2048])
+def test_fft_other_tile_geometries(tile, monkeypatch):
+    """OZK_FFT_TILE selects the workgroup tile (default 1024; 2048 = two passes at 2^22, measured slower —
+    DESIGN.md): every geometry must give the same bytes."""
+    import ctypes
+    import numpy as np
+    from octopuszk_amd import lib
+    L = lib.load()
+    monkeypatch.setenv("OZK_FFT_TILE", str(tile))
+    L.ozk_tuning_reload()
+    try:
+        for logn in (11, 12, 17, 20):
+            n = 1 << logn
+            a = np.random.default_rng(logn).integers(0, 256, size=(n, 32), dtype=np.uint8)
+            a[:, 31] &= 0x1F
+            w = o.to_le32(o.fr_root_of_unity(n))
+            out = ctypes.create_string_buffer(64 * n)
+            lib.check(L.ozk_fft_host(a.ctypes.data_as(ctypes.c_void_p), n, ctypes.cast(ctypes.c_char_p(w), ctypes.c_void_p), 0,
+                                     ctypes.cast(out, ctypes.c_void_p)))
+            assert out.raw == coracle.fft_fr(a.tobytes(), n, w), (tile, logn)
+    finally:
+        monkeypatch.delenv("OZK_FFT_TILE")
+        L.ozk_tuning_reload()
