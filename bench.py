@@ -209,15 +209,19 @@ def main():
         alg_bytes = ALG_BYTES_PER_MUL * n
         k_ms = avg_ms.value
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        traffic = None
+        # PMC counters cannot be collected inside this run (rocprofv3 owns them): `traffic` is the per-launch
+        # figure of the last counter collection (tools/collect_profiles_r02.sh), with the commit it was taken on
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("k_segreduce_level1_hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("k_segreduce_level1_hbm_bytes_per_launch")
+                traffic_src = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, commit %s)" % tj.get("collected_on_commit", "?")
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                     "kernel": "k_segreduce<G1Cfg,true> (level-1 bucket accumulation)",
                     "kernel_avg_ms": round(k_ms, 4), "launches_timed": launches.value,
                     "algorithmic_bytes_per_launch": alg_bytes,
