@@ -5,6 +5,8 @@
  * reference leaks one local ref and one pinned array per element). */
 #include "jni_common.h"
 
+static int ozk_small_le(JNIEnv* env, jbyteArray arr, uint8_t out[32], const char* name);
+
 JNIEXPORT jbyteArray JNICALL Java_algebra_fft_FFTAuxiliary_serialRadix2FFTNativeHelper(
     JNIEnv* env, jclass cls, jobject inputs, jbyteArray omega, jint taskID) {
   (void)cls;
@@ -89,4 +91,26 @@ JNIEXPORT jbyteArray JNICALL Java_algebra_fft_FFTAuxiliary_qapWitnessNativeHelpe
   if (pb) ozk_release(env, b, pb);
   if (pa) ozk_release(env, a, pa);
   return result;
+}
+
+/* ---- OPTIONAL native: the transform over ONE flat byte[] — n x 32 B
+ * little-endian in, n x 32 B out — instead of a java.util.List<byte[]> walked with one JNI call per element
+ * and 64-byte results (algebra_fft_FFTAuxiliary.cu:228-255, FFTAuxiliary.java:41-51). */
+JNIEXPORT jbyteArray JNICALL Java_algebra_fft_FFTAuxiliary_serialRadix2FFTFlatNativeHelper(
+    JNIEnv* env, jclass cls, jbyteArray in, jint n, jbyteArray omega, jint taskID) {
+  (void)cls;
+  if (n <= 0 || (n & (n - 1))) return ozk_throw(env, "FFT input size must be a power of two");
+  uint8_t om[32];
+  if (!ozk_small_le(env, omega, om, "omega")) return NULL;
+  jbyte* p = ozk_borrow(env, in, 32LL * n, "input");
+  if (!p) return NULL;
+  uint8_t* out = (uint8_t*)malloc((size_t)n * 32);
+  int rc = out ? ozk_fft_compact_host((const uint8_t*)p, n, om, taskID, out) : OZK_E_NOMEM;
+  ozk_release(env, in, p);
+  jbyteArray r = NULL;
+  if (!out) r = ozk_throw(env, "out of host memory");
+  else if (rc) r = ozk_throw_last(env, "serialRadix2FFTFlatNativeHelper", rc);
+  else r = ozk_result(env, out, 32LL * n);
+  free(out);
+  return r;
 }

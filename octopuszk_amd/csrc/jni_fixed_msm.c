@@ -70,3 +70,31 @@ JNIEXPORT jbyteArray JNICALL Java_algebra_msm_FixedBaseMSM_fieldBatchMSMNativeHe
   free(out);
   return r;
 }
+
+/* ---- OPTIONAL native (not declared by the reference's Java): the same
+ * batch with COMPACT output — X|Y|Z as 32-byte little-endian values, n x 96 B (G1) / n x 192 B (G2), i.e. half
+ * the bytes of batchMSMNativeHelper (64-byte big-endian coordinates, algebra_msm_FixedBaseMSM.cu:783-787) and
+ * exactly what the variable-base natives take as `bases`, so a key element is never re-marshalled. */
+JNIEXPORT jbyteArray JNICALL Java_algebra_msm_FixedBaseMSM_batchMSMCompactNativeHelper(
+    JNIEnv* env, jclass cls, jint outerc, jint windowSize, jint batch_size, jbyteArray base, jbyteArray scalars,
+    jint BNType, jint taskID) {
+  (void)cls;
+  if (batch_size <= 0) return ozk_throw(env, "batch_size must be positive");
+  const long long per = BNType == OZK_G1 ? 96 : 192;
+  jbyte* b = ozk_borrow(env, base, BNType == OZK_G1 ? 96 : 192, "base");
+  if (!b) return NULL;
+  jbyte* s = ozk_borrow(env, scalars, 32LL * batch_size, "scalars");
+  if (!s) { ozk_release(env, base, b); return NULL; }
+  uint8_t* out = (uint8_t*)malloc((size_t)(per * batch_size));
+  int rc = out ? ozk_fixed_batch_msm_compact_host(outerc, windowSize, batch_size, (const uint8_t*)b, (const uint8_t*)s,
+                                                  BNType, taskID, out)
+               : OZK_E_NOMEM;
+  ozk_release(env, scalars, s);
+  ozk_release(env, base, b);
+  jbyteArray r = NULL;
+  if (!out) r = ozk_throw(env, "out of host memory");
+  else if (rc) r = ozk_throw_last(env, "batchMSMCompactNativeHelper", rc);
+  else r = ozk_result(env, out, per * batch_size);
+  free(out);
+  return r;
+}

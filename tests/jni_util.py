@@ -114,3 +114,23 @@ def prepared_msm(bases, scalars, n, type_, task=0, reps=2):
     rc = m.mock_prepared_msm(SHIM_VAR.encode(), bases, ctypes.c_long(len(bases)), scalars, ctypes.c_long(len(scalars)),
                              n, type_, task, reps, out, ctypes.c_long(384), err)
     return _finish(rc, out, err)
+
+
+def fixed_batch_compact(outerc, ws, n, base, scalars, bn, task=0):
+    m = mock()
+    cap = n * 192
+    out, err = ctypes.create_string_buffer(cap), ctypes.create_string_buffer(1024)
+    m.mock_fixed_batch_compact.restype = ctypes.c_long
+    rc = m.mock_fixed_batch_compact(SHIM_FIXED.encode(), outerc, ws, n, base, ctypes.c_long(len(base)), scalars,
+                                    ctypes.c_long(len(scalars)), bn, task, out, ctypes.c_long(cap), err)
+    return _finish(rc, out, err)
+
+
+def fft_flat(data, n, omega, task=0):
+    m = mock()
+    cap = max(n, 1) * 32
+    out, err = ctypes.create_string_buffer(cap), ctypes.create_string_buffer(1024)
+    m.mock_fft_flat.restype = ctypes.c_long
+    rc = m.mock_fft_flat(SHIM_FFT.encode(), data, ctypes.c_long(len(data)), n, omega, ctypes.c_long(len(omega)), task,
+                         out, ctypes.c_long(cap), err)
+    return _finish(rc, out, err)

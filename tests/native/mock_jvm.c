@@ -241,3 +241,27 @@ long mock_prepared_msm(const char* lib, const void* bases, long bl, const void* 
   fr(a); fr(b);
   return rc;
 }
+
+/* ---- optional compact natives */
+typedef jbyteArray (*fn_fbc)(JNIEnv*, jclass, jint, jint, jint, jbyteArray, jbyteArray, jint, jint);
+long mock_fixed_batch_compact(const char* lib, int outerc, int ws, int n, const void* base, long bl, const void* sc,
+                              long sl, int bn, int task, unsigned char* out, long cap, char* err) {
+  fn_fbc f = (fn_fbc)sym(lib, "Java_algebra_msm_FixedBaseMSM_batchMSMCompactNativeHelper", err);
+  if (!f) return -9;
+  JNIEnv* e = env();
+  MArray *a = mk(base, bl), *b = mk(sc, sl);
+  long rc = finish(f(e, NULL, outerc, ws, n, a, b, bn, task), out, cap, err);
+  fr(a); fr(b);
+  return rc;
+}
+typedef jbyteArray (*fn_fftflat)(JNIEnv*, jclass, jbyteArray, jint, jbyteArray, jint);
+long mock_fft_flat(const char* lib, const void* in, long il, int n, const void* omega, long ol, int task,
+                   unsigned char* out, long cap, char* err) {
+  fn_fftflat f = (fn_fftflat)sym(lib, "Java_algebra_fft_FFTAuxiliary_serialRadix2FFTFlatNativeHelper", err);
+  if (!f) return -9;
+  JNIEnv* e = env();
+  MArray *a = mk(in, il), *om = mk(omega, ol);
+  long rc = finish(f(e, NULL, a, n, om, task), out, cap, err);
+  fr(a); fr(om);
+  return rc;
+}

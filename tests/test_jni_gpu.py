@@ -93,3 +93,37 @@ def test_jni_optional_prepared_bases_natives():
         ju.prepared_msm(bw[:-8], sw, k, 2)          # short bases array -> exception from prepare
     with pytest.raises(ju.JavaException):
         ju.prepared_msm(bw, sw[:-32], k, 2)         # short scalars -> exception from the MSM call
+
+
+def test_jni_optional_compact_natives():
+    # batchMSMCompactNativeHelper / serialRadix2FFTFlatNativeHelper: the
+    # values of the reference-format natives in 32-byte little-endian elements; the fixed-base output is the
+    # variable-base natives' wire-in format, so it feeds variableBaseSerialMSMNativeHelper as it is
+    rng = random.Random(47)
+    sc = [0, 1, o.R - 1] + [rng.randrange(o.R) for _ in range(20)]
+    ws = b"".join(o.to_le32(s) for s in sc)
+    w = 6
+    oc = (254 + w - 1) // w
+    for bn, C, wire in ((1, o.G1, o.g1_to_wire), (2, o.G2, o.g2_to_wire)):
+        B = C.mul(C.one, 4242 + bn)
+        got = ju.fixed_batch_compact(oc, w, len(sc), wire(B), ws, bn)
+        assert got == b"".join(wire(C.to_affine(C.mul(B, s))) for s in sc)
+        # ... and straight into the variable-base native: sum_i t_i (s_i B) = (sum t_i s_i) B
+        ts = [rng.randrange(o.R) for _ in sc]
+        tw = b"".join(o.to_le32(t) for t in ts)
+        acc = sum(t * s for t, s in zip(ts, sc)) % o.R
+        want = C.to_affine(C.mul(B, acc))
+        assert ju.var_msm(got, tw, len(sc), bn) == (o.g1_out_le(want) if bn == 1 else o.g2_out_le(want))
+    with pytest.raises(ju.JavaException):
+        ju.fixed_batch_compact(oc, w, len(sc), o.g1_to_wire(o.G1.one), ws[:-1], 1)
+    n = 512
+    a = [rng.randrange(o.R) for _ in range(n)]
+    om = o.fr_root_of_unity(n)
+    b = list(a)
+    o.serial_radix2_fft(b, om)
+    flat = b"".join(o.to_le32(x) for x in a)
+    assert ju.fft_flat(flat, n, o.to_fft_bytes(om)) == b"".join(o.to_le32(x) for x in b)
+    with pytest.raises(ju.JavaException):
+        ju.fft_flat(flat, 384, o.to_le32(om))
+    with pytest.raises(ju.JavaException):
+        ju.fft_flat(flat[:-32], n, o.to_le32(om))
