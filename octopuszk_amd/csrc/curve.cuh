@@ -16,6 +16,7 @@
 //          upper 32 B zero.
 #pragma once
 #include "ec.cuh"
+#include "quad.cuh"
 
 namespace ozk {
 

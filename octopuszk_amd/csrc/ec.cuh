@@ -310,9 +310,10 @@ OZK_HD Jac<CV> jac_neg(const Jac<CV>& p) {
 }
 
 // G1 over Fq: loop-carried bounds = fixed point of jac_madd (tools/bounds_fixpoint.py)
+struct G1CfgQ;
 struct G1Cfg {
-  using Pair = G1Cfg;                     // serial chains run on one lane
-  static constexpr int PAIR_LANES = 1;
+  using Pair = G1CfgQ;                    // serial chains (Horner, fixed-base doubling chain) run on a lane QUAD
+  static constexpr int PAIR_LANES = 4;    // (quad.cuh)
   static constexpr bool LDS_ACC = false;  // level-1 accumulator in registers (137 VGPRs with the prefetched base, 3 waves per SIMD)
   using EX = Fe<FqParams, 94>;
   using EY = Fe<FqParams, 73>;

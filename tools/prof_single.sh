@@ -1,0 +1,4 @@
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/ps --output-format csv -- python3 $R/bench.py --no-cpu-baseline --steps 10 --in-flight 1 > /dev/null 2>&1
+cd $R && python tools/prof_summary.py gpurun_out/ps > gpurun_out/r2_timeline_single.txt; rm -rf gpurun_out/ps
