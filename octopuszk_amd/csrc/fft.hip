@@ -91,24 +91,40 @@ __device__ __forceinline__ void lds_store(u32* lds, int e, const Fe<FrP, B>& v) 
   for (int i = 0; i < 9; i++) lds[i * TILE + e] = v.l[i];
 }
 
-// stage q (1-based inside the pass) with element bound BIN; recursion unrolls the K stages
-template <int Q, int BIN, int TILE>
-__device__ __forceinline__ void fft_stages(u32* lds, const PassArgs& a, int T, int logT, long long u0) {
-  if (Q > a.K) return;
-  const int M2T = TILE / 2;  // butterflies per stage in the tile
-  for (int b = threadIdx.x; b < M2T; b += TILE / 4) {
-    const int ul = b & (T - 1);
-    const int r = b >> logT;
-    const int low = r & ((1 << (Q - 1)) - 1);
-    const int high = r >> (Q - 1);
-    const int mid0 = (high << Q) | low;
-    const int mid1 = mid0 | (1 << (Q - 1));
-    const long long u = u0 + ul;
-    const long long lo = u & ((1ll << a.sbits) - 1);
-    const long long j = ((long long)low << a.sbits) + lo;
-    const long long ti = j << (a.logn - a.sbits - Q);
+// Index of tile element (mid, ul) of workgroup `blk` in the n-element array.
+//   later passes (sbits > 0): u = blk T + ul enumerates the (hi, lo) pairs around the K bits this pass works
+//     on: i = hi << (sbits + K) | mid << sbits | lo — runs of T consecutive elements (T x 32 B segments);
+//   FIRST pass (sbits = 0): ul sits in the TOP log2(T) bits, i = ul << (logn - log2 T) | blk << K | mid, so that
+//     the bit-reversed SOURCES of a tile come in runs of T consecutive elements too (the reversal turns the top
+//     bits into the lowest ones) instead of 1024 isolated 32-byte reads, and the tile's outputs are T
+//     contiguous runs of 2^K elements.
+template <bool FIRST>
+__device__ __forceinline__ u32 tile_index(const PassArgs& a, u32 blk, int T, int logT, u32 mid, u32 ul) {
+  if (FIRST) return (ul << (a.logn - logT)) | (blk << a.K) | mid;
+  const u32 u = blk * (u32)T + ul;
+  const u32 hi = u >> a.sbits, lo = u & ((1u << a.sbits) - 1u);
+  return (hi << (a.sbits + a.K)) | (mid << a.sbits) | lo;
+}
+// the `lo` part of the twiddle exponent for tile element ul (0 in the first pass: sbits = 0)
+template <bool FIRST>
+__device__ __forceinline__ u32 tile_lo(const PassArgs& a, u32 blk, int T, u32 ul) {
+  if (FIRST) return 0u;
+  return (blk * (u32)T + ul) & ((1u << a.sbits) - 1u);
+}
+
+// ONE stage (Q, 1-based inside the pass) of radix-2 butterflies: TILE / 2 butterflies over TILE / 4 threads
+template <bool FIRST, int Q, int BIN, int TILE>
+__device__ __forceinline__ void fft_stage1(u32* lds, const PassArgs& a, int T, int logT) {
+  for (u32 b = threadIdx.x; b < TILE / 2; b += TILE / 4) {
+    const u32 ul = b & (u32)(T - 1);
+    const u32 r = b >> logT;
+    const u32 low = r & ((1u << (Q - 1)) - 1u);
+    const u32 mid0 = ((r >> (Q - 1)) << Q) | low;
+    const u32 mid1 = mid0 | (1u << (Q - 1));
+    const u32 j = (low << a.sbits) + tile_lo<FIRST>(a, blockIdx.x, T, ul);
+    const u32 ti = j << (a.logn - a.sbits - Q);
     const auto w = ElemTraits<Fe<FrP, 16>>::load(a.tw + (size_t)ti * 8);
-    const int e0 = mid0 * T + ul, e1 = mid1 * T + ul;
+    const u32 e0 = mid0 * T + ul, e1 = mid1 * T + ul;
     const auto x = lds_load<BIN, TILE>(lds, e0);
     const auto y = lds_load<BIN, TILE>(lds, e1);
     const auto t = mul(w, y);                       // plain product (w is Montgomery)
@@ -116,18 +132,68 @@ __device__ __forceinline__ void fft_stages(u32* lds, const PassArgs& a, int T, i
     lds_store<TILE>(lds, e1, Fe<FrP, BIN + 32>(sub(x, t)));
   }
   block_sync();
-  if constexpr ((1 << Q) < TILE) fft_stages<Q + 1, BIN + 32, TILE>(lds, a, T, logT, u0);
 }
 
-template <int BEND, int TILE>
-__device__ __forceinline__ void fft_store_tile(u32* lds, const PassArgs& a, int T, int logT, long long u0,
-                                               bool last) {
-  for (int e = threadIdx.x; e < TILE; e += TILE / 4) {
-    // consecutive lanes -> consecutive ul (contiguous addresses within a T-run)
-    const int ul = e & (T - 1), mid = e >> logT;
-    const long long u = u0 + ul;
-    const long long hi = u >> a.sbits, lo = u & ((1ll << a.sbits) - 1);
-    const long long i = (hi << (a.sbits + a.K)) | ((long long)mid << a.sbits) | lo;
+// TWO stages (Q, Q + 1) in registers: every thread owns the four elements that differ in bits Q - 1 and Q of
+// `mid` — one LDS round trip, one barrier and one index computation for two stages (round 1 ran every stage
+// through LDS; without the multiplications that skeleton alone took 0.29 of the 0.75 ms at 2^22,
+// profiles/r02_fft_experiments.txt).  Twiddles: stage Q pairs (x00, x01) and (x10, x11) with the same w1;
+// stage Q + 1 pairs (., x10') with w2a and (., x11') with w2b (their `low` differs in bit Q - 1).
+template <bool FIRST, int Q, int BIN, int TILE>
+__device__ __forceinline__ void fft_stage2(u32* lds, const PassArgs& a, int T, int logT) {
+  using TW = ElemTraits<Fe<FrP, 16>>;
+  const u32 g = threadIdx.x;                         // TILE / 4 groups, one per thread
+  const u32 ul = g & (u32)(T - 1);
+  const u32 r = g >> logT;
+  const u32 low = r & ((1u << (Q - 1)) - 1u);
+  const u32 m00 = ((r >> (Q - 1)) << (Q + 1)) | low;
+  const u32 m01 = m00 | (1u << (Q - 1)), m10 = m00 | (1u << Q), m11 = m01 | (1u << Q);
+  const u32 lo = tile_lo<FIRST>(a, blockIdx.x, T, ul);
+  const int sh1 = a.logn - a.sbits - Q;
+  const u32 t1 = ((low << a.sbits) + lo) << sh1;
+  const u32 t2a = ((low << a.sbits) + lo) << (sh1 - 1);
+  const u32 t2b = (((low | (1u << (Q - 1))) << a.sbits) + lo) << (sh1 - 1);
+  const auto w1 = TW::load(a.tw + (size_t)t1 * 8);
+  const auto w2a = TW::load(a.tw + (size_t)t2a * 8);
+  const auto w2b = TW::load(a.tw + (size_t)t2b * 8);
+  const u32 e00 = m00 * T + ul, e01 = m01 * T + ul, e10 = m10 * T + ul, e11 = m11 * T + ul;
+  const auto x00 = lds_load<BIN, TILE>(lds, e00);
+  const auto x01 = lds_load<BIN, TILE>(lds, e01);
+  const auto x10 = lds_load<BIN, TILE>(lds, e10);
+  const auto x11 = lds_load<BIN, TILE>(lds, e11);
+  const auto p = mul(w1, x01), q = mul(w1, x11);
+  const Fe<FrP, BIN + 32> a0 = add(x00, p), a1 = sub(x00, p), b0 = add(x10, q), b1 = sub(x10, q);
+  const auto u = mul(w2a, b0), v = mul(w2b, b1);
+  lds_store<TILE>(lds, e00, Fe<FrP, BIN + 64>(add(a0, u)));
+  lds_store<TILE>(lds, e10, Fe<FrP, BIN + 64>(sub(a0, u)));
+  lds_store<TILE>(lds, e01, Fe<FrP, BIN + 64>(add(a1, v)));
+  lds_store<TILE>(lds, e11, Fe<FrP, BIN + 64>(sub(a1, v)));
+  block_sync();
+}
+
+// the K stages of a pass: pairs while two are left, then a single one (K odd)
+template <bool FIRST, int Q, int BIN, int TILE>
+__device__ __forceinline__ void fft_stages(u32* lds, const PassArgs& a, int T, int logT) {
+  if (Q > a.K) return;
+  if constexpr ((2 << Q) <= TILE) {
+    if (Q + 1 <= a.K) {
+      fft_stage2<FIRST, Q, BIN, TILE>(lds, a, T, logT);
+      fft_stages<FIRST, Q + 2, BIN + 64, TILE>(lds, a, T, logT);
+      return;
+    }
+  }
+  fft_stage1<FIRST, Q, BIN, TILE>(lds, a, T, logT);
+  // (a single stage is always the last one of its pass)
+}
+
+template <bool FIRST, int BEND, int TILE>
+__device__ __forceinline__ void fft_store_tile(u32* lds, const PassArgs& a, int T, int logT, bool last) {
+  for (u32 e = threadIdx.x; e < TILE; e += TILE / 4) {
+    // consecutive lanes -> consecutive ul (contiguous addresses within a T-run) in the later passes; in the
+    // first pass consecutive mid (contiguous outputs) — see tile_index
+    const u32 ul = FIRST ? (e >> (31 - __clz(TILE / T))) : (e & (u32)(T - 1));
+    const u32 mid = FIRST ? (e & (u32)(TILE / T - 1)) : (e >> logT);
+    const u32 i = tile_index<FIRST>(a, blockIdx.x, T, logT, mid, ul);
     const auto v = lds_load<BEND, TILE>(lds, mid * T + ul);
     u32 o[8];
     if (last) {
@@ -154,15 +220,13 @@ __global__ void __launch_bounds__(TILE / 4) k_fft_pass(PassArgs a, int last) {
   const int M = 1 << a.K;
   const int T = TILE / M;
   const int logT = 31 - __clz(T);
-  const long long u0 = (long long)blockIdx.x * T;
-  // load the tile: element (mid, ul) <- global index i (FIRST: bit-reversed source)
-  for (int e = threadIdx.x; e < TILE; e += TILE / 4) {
-    const int ul = e & (T - 1), mid = e >> logT;
-    const long long u = u0 + ul;
-    const long long hi = u >> a.sbits, lo = u & ((1ll << a.sbits) - 1);
-    const long long i = (hi << (a.sbits + a.K)) | ((long long)mid << a.sbits) | lo;
-    long long src = i;
-    if (FIRST) src = (long long)(__brev((unsigned)i) >> (32 - a.logn));
+  // load the tile: element (mid, ul) <- global index i (FIRST: bit-reversed source; consecutive lanes take
+  // consecutive ul, i.e. consecutive source elements in both cases)
+  for (u32 e = threadIdx.x; e < TILE; e += TILE / 4) {
+    const u32 ul = e & (u32)(T - 1), mid = e >> logT;
+    const u32 i = tile_index<FIRST>(a, blockIdx.x, T, logT, mid, ul);
+    u32 src = i;
+    if (FIRST) src = __brev(i) >> (32 - a.logn);
     const uint4* sp = reinterpret_cast<const uint4*>(a.in + (size_t)src * 8);
     const uint4 v0 = sp[0], v1 = sp[1];
     const u32 w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
@@ -171,10 +235,10 @@ __global__ void __launch_bounds__(TILE / 4) k_fft_pass(PassArgs a, int last) {
   }
   block_sync();
   constexpr int B0 = 96;  // >= 85 (any 256-bit input) and >= 64 (inter-pass storage)
-  fft_stages<1, B0, TILE>(lds, a, T, logT, u0);
+  fft_stages<FIRST, 1, B0, TILE>(lds, a, T, logT);
   // after K stages the bound is B0 + 32*K <= B0 + 32*log2(TILE)
   constexpr int LOGT = TILE == 2048 ? 11 : (TILE == 1024 ? 10 : 9);
-  fft_store_tile<B0 + 32 * LOGT, TILE>(lds, a, T, logT, u0, last != 0);
+  fft_store_tile<FIRST, B0 + 32 * LOGT, TILE>(lds, a, T, logT, last != 0);
 }
 
 // n == 1 or tiny n (< FFT_TILE): one workgroup, direct global-memory version of the same
@@ -268,7 +332,9 @@ static int fft_core(const u32* d_in, int n, const u32* tw, u32* d_out, int out_s
   int tile = env_int("OZK_FFT_TILE", FFT_TILE_SMALL);
   if (tile != 512 && tile != 1024 && tile != 2048) tile = FFT_TILE_SMALL;
   if (tile > n) tile = FFT_TILE_SMALL;
-  const int maxk = tile == 2048 ? 11 : 8;
+  int maxk = env_int("OZK_FFT_MAXK", tile == 2048 ? 11 : 8);
+  if (maxk < 2) maxk = 2;
+  if (maxk > (tile == 2048 ? 11 : (tile == 1024 ? 10 : 9))) maxk = tile == 2048 ? 11 : (tile == 1024 ? 10 : 9);
   const int npass = (logn + maxk - 1) / maxk;
   int sbits = 0, cur = 0;
   u32* bufs[2] = {buf0, buf1};
@@ -317,10 +383,54 @@ static int fft_core(const u32* d_in, int n, const u32* tw, u32* d_out, int out_s
   return OZK_OK;
 }
 
+// ---- plan cache -------------------------------------------------------------------------------
+// Everything that depends only on the domain — the twiddle table omega^t (n/2 x 32 B: 64 MiB at 2^22), and for
+// the witness map also omega^-1's table, the two coset power tables and the four constants — is built on the
+// first call with a given (device, n, omega[, g]) and kept in library-owned HBM: a prover transforms over ONE
+// domain, seven times per proof (R1CStoQAP.java:163-230), and rebuilding the table was 55 us of a 0.67 ms
+// transform at 2^22 and ~0.2 ms of the 2.4 ms witness map at 2^21.  (The reference recomputes two modular
+// exponentiations per butterfly, algebra_fft_FFTAuxiliary.cu:127,138.)  Four plans, least recently used out;
+// an evicted plan's memory is released with hipFree, which waits for the kernels that may still read it.
+// OZK_FFT_PLAN_CACHE=0 builds the tables per call in the caller's workspace, as round 1 did.
+struct QapConsts;
+struct FftPlan {
+  int device = -1, n = 0;
+  bool qap = false;
+  uint8_t omega[32], g[32];
+  uint8_t* mem = nullptr;
+  u32 *tw_f = nullptr, *tw_i = nullptr, *pw_g = nullptr, *pw_gi = nullptr, *small = nullptr;
+  QapConsts* consts = nullptr;
+  hipEvent_t ready = nullptr;
+  unsigned long long last_use = 0;
+};
+constexpr int FFT_PLANS = 4;
+static pthread_mutex_t g_plan_mu = PTHREAD_MUTEX_INITIALIZER;
+static FftPlan g_plans[FFT_PLANS];
+static unsigned long long g_plan_clock = 0;
+
+static void plan_free(FftPlan& p) {
+  if (p.mem) {
+    hipSetDevice(p.device);
+    hipFree(p.mem);
+  }
+  if (p.ready) hipEventDestroy(p.ready);
+  p = FftPlan();
+}
+
+// returns the cached plan for (current device, n, omega[, g]) with its build enqueued on `st` if it is new;
+// *out stays valid until FFT_PLANS other domains have been used
+static int plan_get(int n, const uint8_t* omega, const uint8_t* g, hipStream_t st, FftPlan** out);
+
 static int fft_dev(const void* d_in, int n, const uint8_t* omega_host, void* d_out, void* wsp, size_t wsb,
                    hipStream_t st, int out_stride = 16) {
   const FftLayout L = fft_layout(n, wsp, wsb);
   if (L.bytes > wsb) return fail(OZK_E_INVALID, "workspace too small: need %zu bytes, got %zu", L.bytes, wsb);
+  if (n >= 2 && env_int("OZK_FFT_PLAN_CACHE", 1)) {
+    FftPlan* pl = nullptr;
+    int rc = plan_get(n, omega_host, nullptr, st, &pl);
+    if (rc) return rc;
+    return fft_core((const u32*)d_in, n, pl->tw_f, (u32*)d_out, out_stride, L.buf[0], L.buf[1], st);
+  }
   OZK_HIP(hipMemcpyAsync(L.omega, omega_host, 32, hipMemcpyHostToDevice, st));
   fft_build_twiddles(L.omega, n, L.small, L.tw, st);
   return fft_core((const u32*)d_in, n, L.tw, (u32*)d_out, out_stride, L.buf[0], L.buf[1], st);
@@ -457,18 +567,114 @@ static QapLayout qap_layout(int m, void* wsp, size_t wsb) {
   return L;
 }
 
+// the domain-dependent part of the witness map: constants, both twiddle tables, both coset power tables
+static int qap_build_tables(QapConsts* consts, u32* small, u32* tw_f, u32* tw_i, u32* pw_g, u32* pw_gi, int m,
+                            const uint8_t* omega_host, const uint8_t* g_host, hipStream_t st) {
+  OZK_HIP(hipMemcpyAsync(consts->omega, omega_host, 32, hipMemcpyHostToDevice, st));
+  OZK_HIP(hipMemcpyAsync(consts->g, g_host, 32, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_qap_consts, dim3(4), dim3(64), 0, st, consts, m);
+  fft_build_twiddles(consts->omega, m, small, tw_f, st);
+  fft_build_twiddles(consts->omega_inv, m, small, tw_i, st);
+  const int hi = (m + TW_LO - 1) / TW_LO + 1;
+  hipLaunchKernelGGL(k_tw_small, dim3((TW_LO + hi + 255) / 256), dim3(256), 0, st, consts->g, TW_LO, hi, pw_g);
+  hipLaunchKernelGGL(k_tw_small, dim3((TW_LO + hi + 255) / 256), dim3(256), 0, st, consts->g_inv, TW_LO, hi, pw_gi);
+  OZK_HIP(hipGetLastError());
+  return OZK_OK;
+}
+
+static int plan_get(int n, const uint8_t* omega, const uint8_t* g, hipStream_t st, FftPlan** out) {
+  int dev = 0;
+  OZK_HIP(hipGetDevice(&dev));
+  pthread_mutex_lock(&g_plan_mu);
+  FftPlan* hit = nullptr;
+  FftPlan* victim = &g_plans[0];
+  for (auto& p : g_plans) {
+    if (p.mem && p.device == dev && p.n == n && p.qap == (g != nullptr) && memcmp(p.omega, omega, 32) == 0 &&
+        (!g || memcmp(p.g, g, 32) == 0)) {
+      hit = &p;
+      break;
+    }
+    if (!p.mem || (victim->mem && p.last_use < victim->last_use)) victim = &p;
+  }
+  int rc = OZK_OK;
+  if (!hit) {
+    plan_free(*victim);
+    FftPlan& p = *victim;
+    p.device = dev;
+    p.n = n;
+    p.qap = g != nullptr;
+    memcpy(p.omega, omega, 32);
+    if (g) memcpy(p.g, g, 32);
+    const int half = n / 2 > 0 ? n / 2 : 1;
+    const int hi = (n + TW_LO - 1) / TW_LO + 1;
+    auto carve = [&](uint8_t* base, FftPlan* dst) {   // same order with and without memory: sizes, then pointers
+      Bump b(base, ~(size_t)0);
+      QapConsts* c = b.take<QapConsts>(1);
+      u32* sm = b.take<u32>((size_t)(TW_LO + hi) * 8);
+      u32* twf = b.take<u32>((size_t)half * 8);
+      u32* twi = g ? b.take<u32>((size_t)half * 8) : nullptr;
+      u32* pg = g ? b.take<u32>((size_t)(TW_LO + hi) * 8) : nullptr;
+      u32* pgi = g ? b.take<u32>((size_t)(TW_LO + hi) * 8) : nullptr;
+      b.take<u32>(64);
+      if (dst) {
+        dst->consts = c;
+        dst->small = sm;
+        dst->tw_f = twf;
+        dst->tw_i = twi;
+        dst->pw_g = pg;
+        dst->pw_gi = pgi;
+      }
+      return b.off;
+    };
+    const size_t bytes = carve(nullptr, nullptr);
+    hipError_t e = hipMalloc((void**)&p.mem, bytes);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p.ready, hipEventDisableTiming);
+    if (e != hipSuccess) {
+      plan_free(p);
+      pthread_mutex_unlock(&g_plan_mu);
+      return fail(OZK_E_NOMEM, "FFT plan allocation (%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    }
+    carve(p.mem, &p);
+    if (g) {
+      rc = qap_build_tables(p.consts, p.small, p.tw_f, p.tw_i, p.pw_g, p.pw_gi, n, omega, g, st);
+    } else {
+      hipError_t e2 = hipMemcpyAsync(p.consts->omega, omega, 32, hipMemcpyHostToDevice, st);
+      if (e2 != hipSuccess) rc = fail(OZK_E_NO_DEVICE, "hipMemcpyAsync failed: %s", hipGetErrorString(e2));
+      else fft_build_twiddles(p.consts->omega, n, p.small, p.tw_f, st);
+    }
+    if (!rc && hipEventRecord(p.ready, st) != hipSuccess) rc = fail(OZK_E_NO_DEVICE, "hipEventRecord failed");
+    if (rc) {
+      plan_free(p);
+      pthread_mutex_unlock(&g_plan_mu);
+      return rc;
+    }
+    hit = &p;
+  }
+  hit->last_use = ++g_plan_clock;
+  hipEvent_t ev = hit->ready;
+  pthread_mutex_unlock(&g_plan_mu);
+  OZK_HIP(hipStreamWaitEvent(st, ev, 0));   // a no-op on the stream that built it
+  *out = hit;
+  return OZK_OK;
+}
+
 static int qap_witness_dev(const void* d_A, const void* d_B, const void* d_C, int m, const uint8_t* omega_host,
                            const uint8_t* g_host, void* d_H, void* wsp, size_t wsb, hipStream_t st) {
-  const QapLayout L = qap_layout(m, wsp, wsb);
+  QapLayout L = qap_layout(m, wsp, wsb);
   if (L.bytes > wsb) return fail(OZK_E_INVALID, "workspace too small: need %zu bytes, got %zu", L.bytes, wsb);
-  OZK_HIP(hipMemcpyAsync(L.consts->omega, omega_host, 32, hipMemcpyHostToDevice, st));
-  OZK_HIP(hipMemcpyAsync(L.consts->g, g_host, 32, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(k_qap_consts, dim3(4), dim3(64), 0, st, L.consts, m);
-  fft_build_twiddles(L.consts->omega, m, L.small, L.tw_f, st);
-  fft_build_twiddles(L.consts->omega_inv, m, L.small, L.tw_i, st);
-  const int hi = (m + TW_LO - 1) / TW_LO + 1;
-  hipLaunchKernelGGL(k_tw_small, dim3((TW_LO + hi + 255) / 256), dim3(256), 0, st, L.consts->g, TW_LO, hi, L.pw_g);
-  hipLaunchKernelGGL(k_tw_small, dim3((TW_LO + hi + 255) / 256), dim3(256), 0, st, L.consts->g_inv, TW_LO, hi, L.pw_gi);
+  if (env_int("OZK_FFT_PLAN_CACHE", 1)) {
+    FftPlan* pl = nullptr;
+    int prc = plan_get(m, omega_host, g_host, st, &pl);
+    if (prc) return prc;
+    L.consts = pl->consts;
+    L.tw_f = pl->tw_f;
+    L.tw_i = pl->tw_i;
+    L.pw_g = pl->pw_g;
+    L.pw_gi = pl->pw_gi;
+  } else {
+    int brc = qap_build_tables(L.consts, L.small, L.tw_f, L.tw_i, L.pw_g, L.pw_gi, m, omega_host, g_host, st);
+    if (brc) return brc;
+  }
   const int TB = 256, nb = (m + TB - 1) / TB;
   const u32* in[3] = {(const u32*)d_A, (const u32*)d_B, (const u32*)d_C};
   u32* v[3] = {L.va, L.vb, L.vc};
@@ -490,6 +696,14 @@ static int qap_witness_dev(const void* d_A, const void* d_B, const void* d_C, in
 }  // namespace ozk
 
 using namespace ozk;
+
+namespace ozk {
+void fft_plan_cache_release() {
+  pthread_mutex_lock(&g_plan_mu);
+  for (auto& p : g_plans) plan_free(p);
+  pthread_mutex_unlock(&g_plan_mu);
+}
+}  // namespace ozk
 
 extern "C" {
 

@@ -252,8 +252,13 @@ int staged_d2h(HostCtx* c, void* h_dst, const void* d_src, size_t bytes, hipStre
 
 }  // namespace ozk
 
+namespace ozk {
+void fft_plan_cache_release();   // fft.hip
+}
+
 extern "C" int ozk_host_cache_release(void) {
   using namespace ozk;
+  fft_plan_cache_release();
   pthread_mutex_lock(&g_pool_mu);
   for (int d = 0; d < MAX_DEVICES; d++) {
     HostCtx* c = g_free[d];
