@@ -188,7 +188,9 @@ __device__ __forceinline__ void fft_stages(u32* lds, const PassArgs& a, int T, i
 
 template <bool FIRST, int BEND, int TILE>
 __device__ __forceinline__ void fft_store_tile(u32* lds, const PassArgs& a, int T, int logT, bool last) {
-  for (u32 e = threadIdx.x; e < TILE; e += TILE / 4) {
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const u32 e = threadIdx.x + (u32)k * (TILE / 4);
     // consecutive lanes -> consecutive ul (contiguous addresses within a T-run) in the later passes; in the
     // first pass consecutive mid (contiguous outputs) — see tile_index
     const u32 ul = FIRST ? (e >> (31 - __clz(TILE / T))) : (e & (u32)(T - 1));
@@ -221,17 +223,30 @@ __global__ void __launch_bounds__(TILE / 4) k_fft_pass(PassArgs a, int last) {
   const int T = TILE / M;
   const int logT = 31 - __clz(T);
   // load the tile: element (mid, ul) <- global index i (FIRST: bit-reversed source; consecutive lanes take
-  // consecutive ul, i.e. consecutive source elements in both cases)
-  for (u32 e = threadIdx.x; e < TILE; e += TILE / 4) {
-    const u32 ul = e & (u32)(T - 1), mid = e >> logT;
-    const u32 i = tile_index<FIRST>(a, blockIdx.x, T, logT, mid, ul);
-    u32 src = i;
-    if (FIRST) src = __brev(i) >> (32 - a.logn);
-    const uint4* sp = reinterpret_cast<const uint4*>(a.in + (size_t)src * 8);
-    const uint4 v0 = sp[0], v1 = sp[1];
-    const u32 w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-    // FIRST: arbitrary 256-bit wire value (bound 85); later passes: stored < 4p
-    lds_store<TILE>(lds, mid * T + ul, unpack<FrP, 85>(w));
+  // consecutive ul, i.e. consecutive source elements in both cases).  All four loads of a thread are issued
+  // before the first one is used: as a plain loop hipcc kept ONE 32-byte load in flight per thread, which made
+  // the tile's trip through HBM latency-bound (~100 us per pass at 2^22, 2.7 TB/s).
+  {
+    uint4 v0[4], v1[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const u32 e = threadIdx.x + (u32)k * (TILE / 4);
+      const u32 ul = e & (u32)(T - 1), mid = e >> logT;
+      const u32 i = tile_index<FIRST>(a, blockIdx.x, T, logT, mid, ul);
+      u32 src = i;
+      if (FIRST) src = __brev(i) >> (32 - a.logn);
+      const uint4* sp = reinterpret_cast<const uint4*>(a.in + (size_t)src * 8);
+      v0[k] = sp[0];
+      v1[k] = sp[1];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const u32 e = threadIdx.x + (u32)k * (TILE / 4);
+      const u32 ul = e & (u32)(T - 1), mid = e >> logT;
+      const u32 w[8] = {v0[k].x, v0[k].y, v0[k].z, v0[k].w, v1[k].x, v1[k].y, v1[k].z, v1[k].w};
+      // FIRST: arbitrary 256-bit wire value (bound 85); later passes: stored < 4p
+      lds_store<TILE>(lds, mid * T + ul, unpack<FrP, 85>(w));
+    }
   }
   block_sync();
   constexpr int B0 = 96;  // >= 85 (any 256-bit input) and >= 64 (inter-pass storage)
