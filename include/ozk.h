@@ -237,6 +237,18 @@ int ozk_fft_compact_dev(const void* d_in, int32_t n, const uint8_t* omega_host32
  * A, B, C: m x 32 B LE (evaluations on the domain S, m a power of two >= 2); omega: the domain's root of
  * unity (SerialFFT.java:24-28), g: the coset shift (Fp.multiplicativeGenerator), 32 B LE each;
  * H: (m + 1) x 32 B LE coefficients (canonical).  */
+/* The step before: the constraint evaluations themselves (R1CStoQAP.java:143-160,195-199 with
+ * LinearCombination.evaluate, relations/objects/LinearCombination.java:39-50 — a term with variable index 0
+ * contributes `one` whatever its coefficient).  A sparse matrix in CSR form resident in HBM — row_ptr: rows + 1
+ * u32 offsets, index: u32 variable indices, coeff: 32-byte LE coefficients, one per term, or NULL when every
+ * coefficient is one — times the assignment (32-byte LE elements): out[i] = sum over row i, rows x 32 B LE,
+ * canonical.  long_rows lists the rows with more than 64 terms (n_long of them, u32): each is cut into 64
+ * slices summed by one workgroup each (workspace: ozk_r1cs_evaluate_workspace_bytes(n_long)); the caller finds
+ * them once per R1CS from row_ptr.  Device pointers; asynchronous on `stream`. */
+size_t ozk_r1cs_evaluate_workspace_bytes(int32_t n_long);
+int ozk_r1cs_evaluate_dev(const void* d_row_ptr, const void* d_index, const void* d_coeff, const void* d_assignment,
+                          int32_t rows, const void* d_long_rows, int32_t n_long, void* d_out, void* d_workspace,
+                          size_t workspace_bytes, void* stream);
 int ozk_qap_witness_host(const uint8_t* A, const uint8_t* B, const uint8_t* C, int32_t m, const uint8_t* omega,
                          const uint8_t* g, int32_t task_id, uint8_t* H);
 size_t ozk_qap_witness_workspace_bytes(int32_t m);

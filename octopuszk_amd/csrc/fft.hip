@@ -708,6 +708,119 @@ static int qap_witness_dev(const void* d_A, const void* d_B, const void* d_C, in
   return OZK_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Constraint evaluation: the step of R1CStoQAP.R1CStoQAPWitness BEFORE its transforms
+// (reductions/r1cs_to_qap/R1CStoQAP.java:143-160,195-199): out[i] = <row i of a sparse matrix, assignment>, with
+// LinearCombination.evaluate's rule that a term with index 0 contributes `one` whatever its coefficient
+// (relations/objects/LinearCombination.java:39-50).  The Java loops over List<Fp> on the CPU ("this evaluation
+// part is costy", R1CStoQAP.java:157); here the R1CS sits in HBM as three CSR matrices and the witness arrives
+// as one 32-byte-per-element buffer, so the whole witness side of a proof stays on the device.
+// One lane per row; rows longer than R1CS_LONG terms (the closing constraint of the reference's synthetic
+// circuits sums every variable, R1CSConstruction.java:87-96) are left to one workgroup each.
+constexpr int R1CS_LONG = 64;
+using FrAcc = Fe<FrP, 32>;
+
+// value of one term (plain, < 2r): z[j], times its coefficient when there is a coefficient array
+__device__ __forceinline__ Fe<FrP, 32> r1cs_term(const u32* __restrict__ idx, const u32* __restrict__ coeff,
+                                                 const u32* __restrict__ z, u32 t) {
+  using ET = ElemTraits<Fe<FrP, 17>>;
+  const u32 j = idx[t];
+  if (j == 0) {
+    Fe<FrP, 32> one = Fe<FrP, 32>(fe_zero<FrP>());
+    one.l[0] = 1;
+    return one;
+  }
+  const uint4* zp = reinterpret_cast<const uint4*>(z + (size_t)j * 8);
+  const uint4 a = zp[0], b = zp[1];
+  const u32 w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  const auto x = unpack<FrP, 85>(w);
+  if (coeff == nullptr) return Fe<FrP, 32>(reduce_to<32>(x));
+  const auto cm = ET::from_wire(coeff + (size_t)t * 8);   // coefficient * R
+  return Fe<FrP, 32>(mul(x, cm));                         // plain product
+}
+
+__global__ void __launch_bounds__(256) k_r1cs_eval(const u32* __restrict__ ptr, const u32* __restrict__ idx,
+                                                   const u32* __restrict__ coeff, const u32* __restrict__ z, int rows,
+                                                   u32* __restrict__ out) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= rows) return;
+  const u32 b = ptr[row], e = ptr[row + 1];
+  if (e - b > (u32)R1CS_LONG) return;
+  FrAcc acc = FrAcc(fe_zero<FrP>());
+  for (u32 t = b; t < e; t++) acc = FrAcc(reduce_to<32>(add(acc, r1cs_term(idx, coeff, z, t))));
+  u32 o[8];
+  pack(canonical(acc), o);
+  uint4* dst = reinterpret_cast<uint4*>(out + (size_t)row * 8);
+  dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+  dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+}
+
+// a long row is cut into R1CS_SPLIT slices, one workgroup each: strided partial sums per thread, a tree over the
+// 256 partials in LDS, one 32-byte partial per slice; k_r1cs_eval_long2 then adds the slices of every long row
+constexpr int R1CS_SPLIT = 64;
+__device__ __forceinline__ FrAcc r1cs_block_sum(FrAcc acc, u32* part) {
+#pragma unroll
+  for (int i = 0; i < 9; i++) part[i * 256 + threadIdx.x] = acc.l[i];
+  block_sync();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      FrAcc x, y;
+#pragma unroll
+      for (int i = 0; i < 9; i++) {
+        x.l[i] = part[i * 256 + threadIdx.x];
+        y.l[i] = part[i * 256 + threadIdx.x + o];
+      }
+      const FrAcc s = FrAcc(reduce_to<32>(add(x, y)));
+#pragma unroll
+      for (int i = 0; i < 9; i++) part[i * 256 + threadIdx.x] = s.l[i];
+    }
+    block_sync();
+  }
+  FrAcc r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = part[i * 256];
+  return r;
+}
+__global__ void __launch_bounds__(256) k_r1cs_eval_long1(const u32* __restrict__ ptr, const u32* __restrict__ idx,
+                                                         const u32* __restrict__ coeff, const u32* __restrict__ z,
+                                                         const u32* __restrict__ long_rows, u32* __restrict__ partial) {
+  __shared__ u32 part[9 * 256];
+  const u32 lr = blockIdx.x / R1CS_SPLIT, sl = blockIdx.x % R1CS_SPLIT;
+  const u32 row = long_rows[lr];
+  const u32 b = ptr[row], e = ptr[row + 1];
+  const u32 per = (e - b + R1CS_SPLIT - 1) / R1CS_SPLIT;
+  const u32 lo = b + sl * per;
+  const u32 hi = (lo + per < e) ? lo + per : e;
+  FrAcc acc = FrAcc(fe_zero<FrP>());
+  for (u32 t = lo + threadIdx.x; t < hi; t += 256) acc = FrAcc(reduce_to<32>(add(acc, r1cs_term(idx, coeff, z, t))));
+  const FrAcc r = r1cs_block_sum(acc, part);
+  if (threadIdx.x == 0) {
+    u32 o[8];
+    pack(canonical(r), o);
+#pragma unroll
+    for (int i = 0; i < 8; i++) partial[(size_t)blockIdx.x * 8 + i] = o[i];
+  }
+}
+__global__ void __launch_bounds__(256) k_r1cs_eval_long2(const u32* __restrict__ long_rows, const u32* __restrict__ partial,
+                                                         u32* __restrict__ out) {
+  __shared__ u32 part[9 * 256];
+  const u32 row = long_rows[blockIdx.x];
+  FrAcc acc = FrAcc(fe_zero<FrP>());
+  if (threadIdx.x < R1CS_SPLIT) {
+    u32 w[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = partial[((size_t)blockIdx.x * R1CS_SPLIT + threadIdx.x) * 8 + i];
+    acc = FrAcc(reduce_to<32>(unpack<FrP, 16>(w)));
+  }
+  const FrAcc r = r1cs_block_sum(acc, part);
+  if (threadIdx.x == 0) {
+    u32 o[8];
+    pack(canonical(r), o);
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[(size_t)row * 8 + i] = o[i];
+  }
+}
+
 }  // namespace ozk
 
 using namespace ozk;
@@ -757,6 +870,33 @@ int ozk_qap_witness_dev(const void* d_A, const void* d_B, const void* d_C, int32
     return fail(OZK_E_INVALID, "domain size %d is not a power of two in [2, 2^28]", m);
   return qap_witness_dev(d_A, d_B, d_C, m, omega_host32, g_host32, d_H, d_workspace, workspace_bytes,
                          (hipStream_t)stream);
+}
+
+size_t ozk_r1cs_evaluate_workspace_bytes(int32_t n_long) {
+  return n_long > 0 ? (size_t)n_long * R1CS_SPLIT * 32 + 256 : 256;
+}
+
+int ozk_r1cs_evaluate_dev(const void* d_row_ptr, const void* d_index, const void* d_coeff, const void* d_assignment,
+                          int32_t rows, const void* d_long_rows, int32_t n_long, void* d_out, void* d_workspace,
+                          size_t workspace_bytes, void* stream) {
+  if (!d_row_ptr || !d_index || !d_assignment || !d_out || (n_long > 0 && (!d_long_rows || !d_workspace)))
+    return fail(OZK_E_INVALID, "null pointer argument");
+  if (rows <= 0 || n_long < 0) return fail(OZK_E_INVALID, "bad row count");
+  if (n_long > 0 && workspace_bytes < ozk_r1cs_evaluate_workspace_bytes(n_long))
+    return fail(OZK_E_INVALID, "workspace too small: need %zu bytes, got %zu", ozk_r1cs_evaluate_workspace_bytes(n_long),
+                workspace_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_r1cs_eval, dim3((rows + 255) / 256), dim3(256), 0, st, (const u32*)d_row_ptr, (const u32*)d_index,
+                     (const u32*)d_coeff, (const u32*)d_assignment, rows, (u32*)d_out);
+  if (n_long > 0) {
+    hipLaunchKernelGGL(k_r1cs_eval_long1, dim3(n_long * R1CS_SPLIT), dim3(256), 0, st, (const u32*)d_row_ptr,
+                       (const u32*)d_index, (const u32*)d_coeff, (const u32*)d_assignment, (const u32*)d_long_rows,
+                       (u32*)d_workspace);
+    hipLaunchKernelGGL(k_r1cs_eval_long2, dim3(n_long), dim3(256), 0, st, (const u32*)d_long_rows,
+                       (const u32*)d_workspace, (u32*)d_out);
+  }
+  OZK_HIP(hipGetLastError());
+  return OZK_OK;
 }
 
 int ozk_qap_witness_host(const uint8_t* A, const uint8_t* B, const uint8_t* C, int32_t m, const uint8_t* omega,

@@ -10,12 +10,13 @@ operation on the GPU through the C ABI of libozk_hip.so and the keys resident in
 
 What runs where.  The reference keeps field elements as BigInteger objects on the JVM heap and crosses
 the JNI for each MSM / batch; here the host side is Python ints (the image has no JDK) for exactly the
-parts the Java does on the CPU (R1CS construction, Lagrange coefficients, the sparse accumulation of
-A_i(t), B_i(t), C_i(t), constraint evaluation), and device buffers for everything else:
+parts the Java does on the CPU in the SETUP (R1CS construction, Lagrange coefficients, the sparse accumulation
+of A_i(t), B_i(t), C_i(t)), and device buffers for everything else:
 
   * setup: the five fixed-base batches write the proving key straight into the wire-in format of the
     variable-base MSM (ozk_fixed_batch_msm_compact_dev), so the key never leaves HBM;
-  * prove: constraint evaluations are uploaded once, ozk_qap_witness_dev leaves coefficientsH in HBM, the
+  * prove: the assignment goes up once (32-byte elements), the constraint matrices sit in HBM as CSR and are
+    evaluated there (ozk_r1cs_evaluate_dev), ozk_qap_witness_dev leaves coefficientsH in HBM, the
     MSMs run over bases prepared once per key (ozk_var_msm_prepare_dev) — G1 through a two-stage pipeline on
     two streams, G2 on a third — and the proof is assembled on the device (ozk_points_sum_dev and one
     5-term MSM) from the MSM results.
@@ -194,6 +195,53 @@ def constraint_evaluations(r1cs: R1CSRelation, full):
             v[nc:nc + ni] = z[:ni]
         ev.append(v)
     return ev, m
+
+
+def assignment_bytes(full) -> np.ndarray:
+    """The assignment as the natives take scalars: 32-byte little-endian elements (the marshalling the Java does
+    per MSM with bigIntegerToByteArrayHelperCGBN, VariableBaseMSM.java:121-131,221-228)."""
+    return np.frombuffer(_le32(full), dtype=np.uint8).copy()
+
+
+class R1CSDevice:
+    """The three constraint matrices resident in HBM as CSR (u32 row offsets / variable indices, optional 32-byte
+    coefficients), with the rows R1CStoQAPWitness adds: A gets `input_i * 0 = 0` rows behind the constraints
+    (R1CStoQAP.java:149-151) and all three are padded with empty rows to the domain size, so that
+    ozk_r1cs_evaluate_dev leaves exactly the vectors the transforms start from."""
+
+    def __init__(self, r1cs: R1CSRelation):
+        nc, ni = r1cs.num_constraints, r1cs.num_inputs
+        self.m = m = lowest_power_of_two(nc + ni)
+        self.mats = []
+        for k, lc in enumerate((r1cs.A, r1cs.B, r1cs.C)):
+            ptr, idx, val = lc.ptr, lc.index, lc.value
+            if k == 0:   # A[nc + i] = z_i
+                ptr = np.concatenate((ptr, ptr[-1] + 1 + np.arange(ni, dtype=np.int64)))
+                idx = np.concatenate((idx, np.arange(ni, dtype=np.int64)))
+                if val is not None:
+                    val = np.concatenate((val, np.ones(ni, dtype=object)))
+            ptr = np.concatenate((ptr, np.full(m + 1 - len(ptr), ptr[-1], dtype=np.int64)))
+            assert len(ptr) == m + 1 and ptr[-1] == len(idx) < 1 << 32
+            long_rows = np.nonzero(np.diff(ptr) > 64)[0].astype(np.uint32)
+            d = dict(ptr=torch.from_numpy(ptr.astype(np.uint32).view(np.uint8).copy()).cuda(),
+                     idx=torch.from_numpy(idx.astype(np.uint32).view(np.uint8).copy()).cuda(),
+                     coeff=None if val is None else _dev_bytes(_le32(int(v) % FR for v in val)),
+                     long=torch.from_numpy(long_rows.view(np.uint8).copy()).cuda() if len(long_rows) else None,
+                     n_long=len(long_rows))
+            self.mats.append(d)
+        self.out = [torch.empty(m * 32, dtype=torch.uint8, device="cuda") for _ in range(3)]
+        self.ws_bytes = int(_lib.load().ozk_r1cs_evaluate_workspace_bytes(max(d["n_long"] for d in self.mats)))
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device="cuda")
+
+    def evaluate(self, d_full):
+        """d_full: the assignment in HBM (num_variables x 32 B).  Asynchronous on the current stream; returns the
+        three evaluation vectors (m x 32 B each)."""
+        L = _lib.load()
+        for d, out in zip(self.mats, self.out):
+            _lib.check(L.ozk_r1cs_evaluate_dev(_ptr(d["ptr"]), _ptr(d["idx"]), _ptr(d["coeff"]) if d["coeff"] is not None else None,
+                                               _ptr(d_full), self.m, _ptr(d["long"]) if d["long"] is not None else None,
+                                               d["n_long"], _ptr(out), _ptr(self.ws), self.ws_bytes, _stream()))
+        return self.out
 
 
 def is_satisfied(r1cs: R1CSRelation, primary, auxiliary) -> bool:
@@ -476,33 +524,35 @@ class SerialProver:
         # results: G1 MSM outputs (192 B each) and G2 outputs (384 B)
         self.o1 = torch.zeros(8, 192, dtype=torch.uint8, device="cuda")
         self.o2 = torch.zeros(3, 384, dtype=torch.uint8, device="cuda")
+        self.r1cs_dev = R1CSDevice(r1cs)   # the constraint matrices, uploaded once per key
         self.omega = ctypes.create_string_buffer(root_of_unity(m).to_bytes(32, "little"), 32)
         self.g = ctypes.create_string_buffer(FR_MULT_GEN.to_bytes(32, "little"), 32)
 
     def close(self):
         self.pipe.close()
 
-    def prove(self, primary, auxiliary, seed: int = SEED, timing=None) -> Proof:
+    def prove(self, primary, auxiliary, seed: int = SEED, timing=None, full_bytes=None) -> Proof:
+        """`full_bytes` (optional): the assignment primary ++ auxiliary already marshalled (assignment_bytes) —
+        what a caller that keeps its witness as bytes hands over; otherwise it is marshalled here."""
         L = _lib.load()
         pk, ni, nw, m = self.pk, self.ni, self.nw, self.m
         T = {}
         t0 = time.perf_counter()
-        full = list(primary) + list(auxiliary)
-        ev, m_ = constraint_evaluations(pk.r1cs, full)           # R1CStoQAP.java:143-160,195-199 (host)
-        assert m_ == m
-        T["evaluate_constraints_host_ms"] = (time.perf_counter() - t0) * 1e3
+        if full_bytes is None:
+            full_bytes = assignment_bytes(list(primary) + list(auxiliary))
+        assert full_bytes.size == self.nv * 32
+        T["marshal_assignment_host_ms"] = (time.perf_counter() - t0) * 1e3
         r = fr_random(seed)                                      # SerialProver.java:58-59
         s = fr_random(seed)
         t1 = time.perf_counter()
-        d_ev = [_dev_bytes(_le32(v)) for v in ev]
-        d_full = _dev_bytes(_le32(full))
+        d_full = torch.from_numpy(full_bytes).cuda()
         tails = _dev_bytes(_le32([1, r, 1, s, 1, 1, s, r, (FR - r * s % FR) % FR]))
         d_prim, d_aux = d_full[:ni * 32], d_full[ni * 32:]
         d_aux_r = torch.cat((d_aux, tails[:64]))                 # auxiliary ++ [1, r]
         d_aux_s = torch.cat((d_aux, tails[64:128]))              # auxiliary ++ [1, s]
         d_fin_sc = tails[128:]                                   # [1, 1, s, r, -rs]
         torch.cuda.synchronize()
-        T["marshal_upload_ms"] = (time.perf_counter() - t1) * 1e3
+        T["upload_ms"] = (time.perf_counter() - t1) * 1e3
         t2 = time.perf_counter()
         main = torch.cuda.current_stream()
         ready = torch.cuda.Event()
@@ -519,7 +569,9 @@ class SerialProver:
             _lib.check(L.ozk_points_sum_dev(_ptr(o2[:2]), 2, 2, _ptr(o2[2]), st2))   # B = primary + (aux + beta + s delta)
             g2_done = torch.cuda.Event()
             g2_done.record(self.s_g2)
-        # witness map (SerialProver.java:36-41): coefficientsH stay in HBM
+        # witness map (SerialProver.java:36-41): constraint evaluations (R1CStoQAP.java:143-160,195-199) and the
+        # seven transforms on the device; coefficientsH stay in HBM
+        d_ev = self.r1cs_dev.evaluate(d_full)
         _lib.check(L.ozk_qap_witness_dev(_ptr(d_ev[0]), _ptr(d_ev[1]), _ptr(d_ev[2]), m, ctypes.cast(self.omega, ctypes.c_void_p),
                                          ctypes.cast(self.g, ctypes.c_void_p), _ptr(self.d_h), _ptr(self.q_ws),
                                          self.q_ws_bytes, int(main.cuda_stream)))
@@ -545,7 +597,7 @@ class SerialProver:
         torch.cuda.synchronize()
         T["gpu_ms"] = (time.perf_counter() - t2) * 1e3
         proof = Proof(bytes(o1[6].cpu().numpy()), bytes(o2[2].cpu().numpy()), bytes(c_out.cpu().numpy()))
-        self._keep = (d_ev, d_full, tails, d_aux_r, d_aux_s, fin_bases)
+        self._keep = (d_full, tails, d_aux_r, d_aux_s, fin_bases)
         if timing is not None:
             timing.update(T)
         return proof

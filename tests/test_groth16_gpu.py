@@ -53,6 +53,13 @@ def test_groth16_2p10_bit_exact_vs_oracle():
 
     prover = z.SerialProver(pk)
     try:
+        # constraint evaluation on the device == LinearCombination.evaluate on the host == the oracle
+        import torch
+        ev_host, _ = z.constraint_evaluations(r1cs, primary + auxiliary)
+        ev_dev = prover.r1cs_dev.evaluate(torch.from_numpy(z.assignment_bytes(primary + auxiliary)).cuda())
+        torch.cuda.synchronize()
+        for k in range(3):
+            assert bytes(ev_dev[k].cpu().numpy()) == z._le32(ev_host[k]), "ABC"[k]
         for _ in range(2):   # second call: buffers reused
             proof = prover.prove(primary, auxiliary)
             assert prover.coefficients_h() == info["H"]
@@ -106,3 +113,33 @@ def _check_by_known_scalars(nc, ni):
     assert proof.g_a == o.g1_out_le(o.G1.to_affine(o.G1.mul(o.G1.one, a * gen % R)))
     assert proof.g_b == o.g2_out_le(o.G2.to_affine(o.G2.mul(o.G2.one, b * gen % R)))
     assert proof.g_c == o.g1_out_le(o.G1.to_affine(o.G1.mul(o.G1.one, c * gen % R)))
+
+
+def test_r1cs_evaluate_with_coefficients_and_long_rows():
+    """ozk_r1cs_evaluate_dev on a matrix the synthetic circuits do not produce: random coefficients, empty rows,
+    index-0 terms (which count as `one`, LinearCombination.java:45), rows of 1 ... 700 terms."""
+    import numpy as np
+    import torch
+    from octopuszk_amd import zksnark as z
+    rng = np.random.default_rng(7)
+    nv, rows = 900, 300
+    full = [1] + [int.from_bytes(rng.bytes(32), "little") % o.R for _ in range(nv - 1)]
+    lens = rng.integers(0, 6, size=rows)
+    lens[5], lens[17], lens[250] = 700, 65, 64
+    ptr = np.concatenate(([0], np.cumsum(lens)))
+    idx = rng.integers(0, nv, size=int(ptr[-1]))
+    val = np.array([int.from_bytes(rng.bytes(32), "little") % o.R for _ in range(int(ptr[-1]))], dtype=object)
+    val[3] = 0
+    lc = z.LinearCombinations(ptr, idx, val)
+    want = lc.evaluate(np.array(full, dtype=object))
+    oracle_rows = [g.lc_evaluate([(int(idx[t]), int(val[t])) for t in range(ptr[i], ptr[i + 1])], full) for i in range(rows)]
+    assert [int(x) for x in want] == oracle_rows
+    r1 = z.R1CSRelation(lc, lc, lc, 1, nv - 1)
+    r1.num_constraints = rows
+    dev = z.R1CSDevice(r1)
+    ev = dev.evaluate(torch.from_numpy(z.assignment_bytes(full)).cuda())
+    torch.cuda.synchronize()
+    got = bytes(ev[1].cpu().numpy())          # B: no extra rows
+    assert got[:rows * 32] == z._le32(oracle_rows) and not any(got[rows * 32:])
+    got_a = bytes(ev[0].cpu().numpy())        # A: row `rows` is the extra input_0 * 0 = 0 row, i.e. z_0 = 1
+    assert got_a[:rows * 32] == z._le32(oracle_rows) and got_a[rows * 32:(rows + 1) * 32] == z._le32([1])
