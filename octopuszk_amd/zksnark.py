@@ -19,7 +19,7 @@ of A_i(t), B_i(t), C_i(t)), and device buffers for everything else:
     evaluated there (ozk_r1cs_evaluate_dev), ozk_qap_witness_dev leaves coefficientsH in HBM, the
     MSMs run over bases prepared once per key (ozk_var_msm_prepare_dev) — G1 through a two-stage pipeline on
     two streams, G2 on a third — and the proof is assembled on the device (ozk_points_sum_dev and one
-    5-term MSM) from the MSM results.
+    3-term MSM, s A + r B1 - r s delta, on a fourth stream behind the long MSMs) from the MSM results.
 
 Proof elements are returned in the wire-out format of the variable-base natives (affine-normalised,
 64-byte little-endian coordinates).  There is no CPU fallback: without the HIP library nothing here works.
@@ -512,17 +512,18 @@ class SerialProver:
         self.qh = prep(pk.query_h, m + 1, 1)
         self.dabc = prep(pk.delta_abc_g1, nw, 1)
         torch.cuda.synchronize()
-        self.pipe = _G1Pipeline([ni, nw + 2, m + 1, nw, 5])
+        self.pipe = _G1Pipeline([ni, nw + 2, m + 1, nw])
         self.g2_ws_bytes = max(int(L.ozk_var_msm_workspace_bytes(n, 2)) for n in (ni, nw + 2))
         self.g2_ws = torch.empty(self.g2_ws_bytes, dtype=torch.uint8, device="cuda")
         self.s_g2 = torch.cuda.Stream()
-        self.fin_ws_bytes = int(L.ozk_var_msm_workspace_bytes(5, 1))
+        self.s_fin = torch.cuda.Stream()
+        self.fin_ws_bytes = int(L.ozk_var_msm_workspace_bytes(3, 1))
         self.fin_ws = torch.empty(self.fin_ws_bytes, dtype=torch.uint8, device="cuda")
         self.q_ws_bytes = int(L.ozk_qap_witness_workspace_bytes(m))
         self.q_ws = torch.empty(self.q_ws_bytes, dtype=torch.uint8, device="cuda")
         self.d_h = torch.empty((m + 1) * 32, dtype=torch.uint8, device="cuda")
         # results: G1 MSM outputs (192 B each) and G2 outputs (384 B)
-        self.o1 = torch.zeros(8, 192, dtype=torch.uint8, device="cuda")
+        self.o1 = torch.zeros(9, 192, dtype=torch.uint8, device="cuda")
         self.o2 = torch.zeros(3, 384, dtype=torch.uint8, device="cuda")
         self.r1cs_dev = R1CSDevice(r1cs)   # the constraint matrices, uploaded once per key
         self.omega = ctypes.create_string_buffer(root_of_unity(m).to_bytes(32, "little"), 32)
@@ -550,7 +551,7 @@ class SerialProver:
         d_prim, d_aux = d_full[:ni * 32], d_full[ni * 32:]
         d_aux_r = torch.cat((d_aux, tails[:64]))                 # auxiliary ++ [1, r]
         d_aux_s = torch.cat((d_aux, tails[64:128]))              # auxiliary ++ [1, s]
-        d_fin_sc = tails[128:]                                   # [1, 1, s, r, -rs]
+        d_fin_sc = tails[192:]                                   # [s, r, -rs]
         torch.cuda.synchronize()
         T["upload_ms"] = (time.perf_counter() - t1) * 1e3
         t2 = time.perf_counter()
@@ -579,25 +580,35 @@ class SerialProver:
         evs = [p.submit(self.qa_p, d_prim, ni, o1[0]),           # :76-79 query A
                p.submit(self.qa_w, d_aux_r, nw + 2, o1[1]),
                p.submit(self.qb1_p, d_prim, ni, o1[2]),          # :82-88 query B, G1 half
-               p.submit(self.qb1_w, d_aux_s, nw + 2, o1[3]),
-               p.submit(self.qh, self.d_h, m + 1, o1[4]),        # :91-93 query H
-               p.submit(self.dabc, d_aux, nw, o1[5])]            # :98-101 deltaABC
-        for e in evs:
+               p.submit(self.qb1_w, d_aux_s, nw + 2, o1[3])]
+        # A and B1 are complete once those four tails are: their share of C — s A + r B1 - r s delta (:114) —
+        # is a 3-term MSM that runs on its own stream while the two long MSMs (H, deltaABC) still occupy the pipeline
+        with torch.cuda.stream(self.s_fin):
+            for e in evs:
+                self.s_fin.wait_event(e)
+            sf = _stream()
+            _lib.check(L.ozk_points_sum_dev(_ptr(o1[0:2]), 2, 1, _ptr(o1[6]), sf))       # A
+            _lib.check(L.ozk_points_sum_dev(_ptr(o1[2:4]), 2, 1, _ptr(o1[7]), sf))       # B in G1
+            fin_bases = torch.cat((wire_out_to_in(o1[6], 1), wire_out_to_in(o1[7], 1), pk.delta_g1))
+            _lib.check(L.ozk_var_msm_dev(_ptr(fin_bases), _ptr(d_fin_sc), 3, 1, _ptr(o1[8]), _ptr(self.fin_ws),
+                                         self.fin_ws_bytes, sf))
+            fin_done = torch.cuda.Event()
+            fin_done.record(self.s_fin)
+        evs2 = [p.submit(self.qh, self.d_h, m + 1, o1[4]),       # :91-93 query H
+                p.submit(self.dabc, d_aux, nw, o1[5])]           # :98-101 deltaABC
+        for e in evs2:
             main.wait_event(e)
+        main.wait_event(fin_done)
         st = int(main.cuda_stream)
-        _lib.check(L.ozk_points_sum_dev(_ptr(o1[0:2]), 2, 1, _ptr(o1[6]), st))       # A
-        _lib.check(L.ozk_points_sum_dev(_ptr(o1[2:4]), 2, 1, _ptr(o1[7]), st))       # B in G1
-        # C = evaluationABC + H(t)Z(t)/delta + s A + r B1 - r s delta (:102,:114): one 5-term MSM
-        fin_bases = torch.cat((wire_out_to_in(o1[5], 1), wire_out_to_in(o1[4], 1), wire_out_to_in(o1[6], 1),
-                               wire_out_to_in(o1[7], 1), pk.delta_g1))
+        # C = evaluationABC + H(t)Z(t)/delta + (s A + r B1 - r s delta)   (:102,:114)
+        c_in = torch.cat((o1[5], o1[4], o1[8]))
         c_out = torch.zeros(192, dtype=torch.uint8, device="cuda")
-        _lib.check(L.ozk_var_msm_dev(_ptr(fin_bases), _ptr(d_fin_sc), 5, 1, _ptr(c_out), _ptr(self.fin_ws),
-                                     self.fin_ws_bytes, st))
+        _lib.check(L.ozk_points_sum_dev(_ptr(c_in), 3, 1, _ptr(c_out), st))
         main.wait_event(g2_done)
         torch.cuda.synchronize()
         T["gpu_ms"] = (time.perf_counter() - t2) * 1e3
         proof = Proof(bytes(o1[6].cpu().numpy()), bytes(o2[2].cpu().numpy()), bytes(c_out.cpu().numpy()))
-        self._keep = (d_full, tails, d_aux_r, d_aux_s, fin_bases)
+        self._keep = (d_full, tails, d_aux_r, d_aux_s, fin_bases, c_in)
         if timing is not None:
             timing.update(T)
         return proof
