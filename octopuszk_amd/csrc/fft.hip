@@ -134,17 +134,57 @@ __device__ __forceinline__ void fft_stage1(u32* lds, const PassArgs& a, int T, i
   block_sync();
 }
 
+// one tile element straight from / to global memory (the first / last stages of a pass skip LDS)
+template <bool FIRST, int TILE>
+__device__ __forceinline__ void gload(const PassArgs& a, int T, int logT, u32 mid, u32 ul, uint4& v0, uint4& v1) {
+  const u32 i = tile_index<FIRST>(a, blockIdx.x, T, logT, mid, ul);
+  u32 src = i;
+  if (FIRST) src = __brev(i) >> (32 - a.logn);
+  const uint4* sp = reinterpret_cast<const uint4*>(a.in + (size_t)src * 8);
+  v0 = sp[0];
+  v1 = sp[1];
+}
+__device__ __forceinline__ Fe<FrP, 96> gunpack(const uint4& v0, const uint4& v1) {
+  const u32 w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+  return Fe<FrP, 96>(unpack<FrP, 85>(w));   // FIRST: arbitrary 256-bit wire value (85); later passes: stored < 4p
+}
+template <bool FIRST, int TILE, int B>
+__device__ __forceinline__ void gstore(const PassArgs& a, int T, int logT, u32 mid, u32 ul, const Fe<FrP, B>& v, bool last) {
+  const u32 i = tile_index<FIRST>(a, blockIdx.x, T, logT, mid, ul);
+  u32 o[8];
+  if (last) {
+    pack(canonical(v), o);
+    uint4* dst = reinterpret_cast<uint4*>(a.out + (size_t)i * a.out_stride);
+    dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+    dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+    if (a.out_stride == 16) {
+      dst[2] = make_uint4(0, 0, 0, 0);
+      dst[3] = make_uint4(0, 0, 0, 0);
+    }
+  } else {
+    pack(reduce_to<64>(v), o);
+    uint4* dst = reinterpret_cast<uint4*>(a.out + (size_t)i * 8);
+    dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+    dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+  }
+}
+
 // TWO stages (Q, Q + 1) in registers: every thread owns the four elements that differ in bits Q - 1 and Q of
 // `mid` — one LDS round trip, one barrier and one index computation for two stages (round 1 ran every stage
 // through LDS; without the multiplications that skeleton alone took 0.29 of the 0.75 ms at 2^22,
 // profiles/r02_fft_experiments.txt).  Twiddles: stage Q pairs (x00, x01) and (x10, x11) with the same w1;
 // stage Q + 1 pairs (., x10') with w2a and (., x11') with w2b (their `low` differs in bit Q - 1).
-template <bool FIRST, int Q, int BIN, int TILE>
-__device__ __forceinline__ void fft_stage2(u32* lds, const PassArgs& a, int T, int logT) {
+// SRC_G: the four inputs come straight from global memory (the first pair of a pass, Q = 1);
+// DST_G: the four outputs go straight to global memory (the last pair) — two LDS round trips fewer per pass.
+template <bool FIRST, int Q, int BIN, int TILE, bool SRC_G, bool DST_G>
+__device__ __forceinline__ void fft_stage2(u32* lds, const PassArgs& a, int T, int logT, bool last) {
   using TW = ElemTraits<Fe<FrP, 16>>;
   const u32 g = threadIdx.x;                         // TILE / 4 groups, one per thread
-  const u32 ul = g & (u32)(T - 1);
-  const u32 r = g >> logT;
+  // lane -> (ul, r): ul fastest, so that a wave's global accesses come in runs of T consecutive elements; the
+  // first pass writes consecutive `mid` to consecutive addresses instead (tile_index), so there r is fastest
+  const int logR = 31 - __clz(TILE / 4 / T);
+  const u32 ul = (FIRST && DST_G) ? (g >> logR) : (g & (u32)(T - 1));
+  const u32 r = (FIRST && DST_G) ? (g & ((1u << logR) - 1u)) : (g >> logT);
   const u32 low = r & ((1u << (Q - 1)) - 1u);
   const u32 m00 = ((r >> (Q - 1)) << (Q + 1)) | low;
   const u32 m01 = m00 | (1u << (Q - 1)), m10 = m00 | (1u << Q), m11 = m01 | (1u << Q);
@@ -153,37 +193,96 @@ __device__ __forceinline__ void fft_stage2(u32* lds, const PassArgs& a, int T, i
   const u32 t1 = ((low << a.sbits) + lo) << sh1;
   const u32 t2a = ((low << a.sbits) + lo) << (sh1 - 1);
   const u32 t2b = (((low | (1u << (Q - 1))) << a.sbits) + lo) << (sh1 - 1);
+  const u32 e00 = m00 * T + ul, e01 = m01 * T + ul, e10 = m10 * T + ul, e11 = m11 * T + ul;
+  Fe<FrP, BIN> x00, x01, x10, x11;
+  if constexpr (SRC_G) {
+    static_assert(BIN >= 96, "bound of a freshly loaded element");
+    uint4 v0[4], v1[4];
+    gload<FIRST, TILE>(a, T, logT, m00, ul, v0[0], v1[0]);
+    gload<FIRST, TILE>(a, T, logT, m01, ul, v0[1], v1[1]);
+    gload<FIRST, TILE>(a, T, logT, m10, ul, v0[2], v1[2]);
+    gload<FIRST, TILE>(a, T, logT, m11, ul, v0[3], v1[3]);
+    x00 = gunpack(v0[0], v1[0]);
+    x01 = gunpack(v0[1], v1[1]);
+    x10 = gunpack(v0[2], v1[2]);
+    x11 = gunpack(v0[3], v1[3]);
+  } else {
+    x00 = lds_load<BIN, TILE>(lds, e00);
+    x01 = lds_load<BIN, TILE>(lds, e01);
+    x10 = lds_load<BIN, TILE>(lds, e10);
+    x11 = lds_load<BIN, TILE>(lds, e11);
+  }
   const auto w1 = TW::load(a.tw + (size_t)t1 * 8);
   const auto w2a = TW::load(a.tw + (size_t)t2a * 8);
   const auto w2b = TW::load(a.tw + (size_t)t2b * 8);
-  const u32 e00 = m00 * T + ul, e01 = m01 * T + ul, e10 = m10 * T + ul, e11 = m11 * T + ul;
-  const auto x00 = lds_load<BIN, TILE>(lds, e00);
-  const auto x01 = lds_load<BIN, TILE>(lds, e01);
-  const auto x10 = lds_load<BIN, TILE>(lds, e10);
-  const auto x11 = lds_load<BIN, TILE>(lds, e11);
   const auto p = mul(w1, x01), q = mul(w1, x11);
   const Fe<FrP, BIN + 32> a0 = add(x00, p), a1 = sub(x00, p), b0 = add(x10, q), b1 = sub(x10, q);
   const auto u = mul(w2a, b0), v = mul(w2b, b1);
-  lds_store<TILE>(lds, e00, Fe<FrP, BIN + 64>(add(a0, u)));
-  lds_store<TILE>(lds, e10, Fe<FrP, BIN + 64>(sub(a0, u)));
-  lds_store<TILE>(lds, e01, Fe<FrP, BIN + 64>(add(a1, v)));
-  lds_store<TILE>(lds, e11, Fe<FrP, BIN + 64>(sub(a1, v)));
+  const Fe<FrP, BIN + 64> y00 = add(a0, u), y10 = sub(a0, u), y01 = add(a1, v), y11 = sub(a1, v);
+  if constexpr (DST_G) {
+    gstore<FIRST, TILE>(a, T, logT, m00, ul, y00, last);
+    gstore<FIRST, TILE>(a, T, logT, m01, ul, y01, last);
+    gstore<FIRST, TILE>(a, T, logT, m10, ul, y10, last);
+    gstore<FIRST, TILE>(a, T, logT, m11, ul, y11, last);
+  } else {
+    lds_store<TILE>(lds, e00, y00);
+    lds_store<TILE>(lds, e10, y10);
+    lds_store<TILE>(lds, e01, y01);
+    lds_store<TILE>(lds, e11, y11);
+    block_sync();
+  }
+}
+
+// stage 1 alone, inputs from global memory, outputs to LDS (passes with an odd number of stages open with it):
+// the thread's four elements mid = 4r .. 4r + 3 are two butterflies with the same twiddle
+template <bool FIRST, int TILE>
+__device__ __forceinline__ void fft_stage1_from_global(u32* lds, const PassArgs& a, int T, int logT) {
+  const u32 g = threadIdx.x;
+  const u32 ul = g & (u32)(T - 1), r = g >> logT;
+  const u32 m0 = r << 2;
+  uint4 v0[4], v1[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) gload<FIRST, TILE>(a, T, logT, m0 + k, ul, v0[k], v1[k]);
+  const u32 lo = tile_lo<FIRST>(a, blockIdx.x, T, ul);
+  const auto w = ElemTraits<Fe<FrP, 16>>::load(a.tw + (size_t)(lo << (a.logn - a.sbits - 1)) * 8);
+#pragma unroll
+  for (int k = 0; k < 4; k += 2) {
+    const auto x = gunpack(v0[k], v1[k]), y = gunpack(v0[k + 1], v1[k + 1]);
+    const auto t = mul(w, y);
+    lds_store<TILE>(lds, (m0 + k) * T + ul, Fe<FrP, 128>(add(x, t)));
+    lds_store<TILE>(lds, (m0 + k + 1) * T + ul, Fe<FrP, 128>(sub(x, t)));
+  }
   block_sync();
 }
 
-// the K stages of a pass: pairs while two are left, then a single one (K odd)
+// stages Q .. K of a pass whose first stage(s) already ran from global memory: pairs, the last one to global
+template <bool FIRST, int Q, int BIN, int TILE>
+__device__ __forceinline__ void fft_pairs_to_global(u32* lds, const PassArgs& a, int T, int logT, bool last) {
+  if constexpr ((2 << Q) <= TILE) {
+    if (Q + 1 == a.K) {
+      fft_stage2<FIRST, Q, BIN, TILE, false, true>(lds, a, T, logT, last);
+      return;
+    }
+    if (Q + 1 < a.K) {
+      fft_stage2<FIRST, Q, BIN, TILE, false, false>(lds, a, T, logT, last);
+      fft_pairs_to_global<FIRST, Q + 2, BIN + 64, TILE>(lds, a, T, logT, last);
+    }
+  }
+}
+
+// the K stages of a pass through LDS: pairs while two are left, then a single one (K odd).  Used for short
+// passes (K < 3); longer ones go through fft_pairs_to_global
 template <bool FIRST, int Q, int BIN, int TILE>
 __device__ __forceinline__ void fft_stages(u32* lds, const PassArgs& a, int T, int logT) {
   if (Q > a.K) return;
-  if constexpr ((2 << Q) <= TILE) {
+  if constexpr (Q <= 2) {
     if (Q + 1 <= a.K) {
-      fft_stage2<FIRST, Q, BIN, TILE>(lds, a, T, logT);
+      fft_stage2<FIRST, Q, BIN, TILE, false, false>(lds, a, T, logT, false);
       fft_stages<FIRST, Q + 2, BIN + 64, TILE>(lds, a, T, logT);
       return;
     }
+    fft_stage1<FIRST, Q, BIN, TILE>(lds, a, T, logT);
   }
-  fft_stage1<FIRST, Q, BIN, TILE>(lds, a, T, logT);
-  // (a single stage is always the last one of its pass)
 }
 
 template <bool FIRST, int BEND, int TILE>
@@ -222,37 +321,36 @@ __global__ void __launch_bounds__(TILE / 4) k_fft_pass(PassArgs a, int last) {
   const int M = 1 << a.K;
   const int T = TILE / M;
   const int logT = 31 - __clz(T);
-  // load the tile: element (mid, ul) <- global index i (FIRST: bit-reversed source; consecutive lanes take
-  // consecutive ul, i.e. consecutive source elements in both cases).  All four loads of a thread are issued
-  // before the first one is used: as a plain loop hipcc kept ONE 32-byte load in flight per thread, which made
-  // the tile's trip through HBM latency-bound (~100 us per pass at 2^22, 2.7 TB/s).
+  constexpr int B0 = 96;  // >= 85 (any 256-bit input) and >= 64 (inter-pass storage)
+  constexpr int LOGT = TILE == 2048 ? 11 : (TILE == 1024 ? 10 : 9);
+  if (a.K >= 3) {
+    // the first stage(s) read the tile from global memory, the last pair writes it back: LDS is only the
+    // exchange between the stage pairs in between (three round trips instead of five for 8 stages)
+    if (a.K & 1) {
+      fft_stage1_from_global<FIRST, TILE>(lds, a, T, logT);
+      fft_pairs_to_global<FIRST, 2, B0 + 32, TILE>(lds, a, T, logT, last != 0);
+    } else {
+      fft_stage2<FIRST, 1, B0, TILE, true, false>(lds, a, T, logT, false);
+      fft_pairs_to_global<FIRST, 3, B0 + 64, TILE>(lds, a, T, logT, last != 0);
+    }
+    return;
+  }
+  // short passes (tiny transforms): tile in, stages through LDS, tile out
   {
     uint4 v0[4], v1[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const u32 e = threadIdx.x + (u32)k * (TILE / 4);
-      const u32 ul = e & (u32)(T - 1), mid = e >> logT;
-      const u32 i = tile_index<FIRST>(a, blockIdx.x, T, logT, mid, ul);
-      u32 src = i;
-      if (FIRST) src = __brev(i) >> (32 - a.logn);
-      const uint4* sp = reinterpret_cast<const uint4*>(a.in + (size_t)src * 8);
-      v0[k] = sp[0];
-      v1[k] = sp[1];
+      gload<FIRST, TILE>(a, T, logT, e >> logT, e & (u32)(T - 1), v0[k], v1[k]);
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const u32 e = threadIdx.x + (u32)k * (TILE / 4);
-      const u32 ul = e & (u32)(T - 1), mid = e >> logT;
-      const u32 w[8] = {v0[k].x, v0[k].y, v0[k].z, v0[k].w, v1[k].x, v1[k].y, v1[k].z, v1[k].w};
-      // FIRST: arbitrary 256-bit wire value (bound 85); later passes: stored < 4p
-      lds_store<TILE>(lds, mid * T + ul, unpack<FrP, 85>(w));
+      lds_store<TILE>(lds, (e >> logT) * T + (e & (u32)(T - 1)), gunpack(v0[k], v1[k]));
     }
   }
   block_sync();
-  constexpr int B0 = 96;  // >= 85 (any 256-bit input) and >= 64 (inter-pass storage)
   fft_stages<FIRST, 1, B0, TILE>(lds, a, T, logT);
-  // after K stages the bound is B0 + 32*K <= B0 + 32*log2(TILE)
-  constexpr int LOGT = TILE == 2048 ? 11 : (TILE == 1024 ? 10 : 9);
   fft_store_tile<FIRST, B0 + 32 * LOGT, TILE>(lds, a, T, logT, last != 0);
 }
 
