@@ -96,6 +96,7 @@ def main():
                     help="STRONG scaling: one MSM of 2^TOTAL_LOGN pairs sharded over the ranks (BASELINE.json configs[3]: "
                          "24 over 8 GPUs = 2^21 per rank); the default is weak scaling, 2^LOGN pairs per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-streams-leg", action="store_true", help="skip the secondary three-streams throughput figure")
     ap.add_argument("--prepared", action="store_true",
                     help="bases prepared once outside the timed region (ozk_var_msm_prepare_dev): NOT the "
                          "BASELINE.json workload, whose every MSM starts from the JNI wire bytes")
@@ -230,6 +231,25 @@ def main():
         torch.cuda.synchronize()
         lat.append(time.perf_counter() - l0)
     single_ms = sorted(lat)[len(lat) // 2] * 1e3
+    # Secondary figure (never `value`): the same MSMs issued as three free-running streams — how concurrent
+    # prover threads drive the library.  Higher throughput (everything but the bucket accumulation of one MSM runs
+    # inside the accumulation of the others), but the co-running kernels stretch each accumulation launch, so the
+    # default schedule, which keeps that kernel's duration clean for `roofline`, stays the timed one.
+    streams3 = None
+    if world == 1 and args.schedule == "pipeline" and not args.no_streams_leg:
+        ws3 = [dev.VarMsmWorkspace(n, 1) for _ in range(3)]
+        st3 = [torch.cuda.Stream() for _ in range(3)]
+        k3 = max(6, min(args.steps, 30))
+        for rep in range(2):            # first round: warm-up
+            torch.cuda.synchronize()
+            s0 = time.perf_counter()
+            for i in range(k3):
+                with torch.cuda.stream(st3[i % 3]):
+                    ws3[i % 3].run(msm_bases, scalars, prepared=args.prepared)
+            torch.cuda.synchronize()
+            s1 = time.perf_counter()
+        streams3 = round(n * k3 / (s1 - s0) / 1e6, 3)
+        del ws3
 
     elapsed = t1 - t0
     if world > 1:
@@ -303,6 +323,7 @@ def main():
                            "prepared_bases": bool(args.prepared),
                            "msms_in_flight": max(1, args.in_flight), "schedule": args.schedule,
                            "single_msm_latency_ms": round(single_ms, 3),
+                           "three_streams_Mscalar_mul_s": streams3,
                            "result_hex": result_bytes.hex(),
                            "parallelism": "index-range shard x%d, RCCL all-gather of 192-B partials + HIP point sum" % world},
                 "roofline": roofline, "cpu_baseline": cpu}

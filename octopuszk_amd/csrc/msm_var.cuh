@@ -734,6 +734,33 @@ struct RunAcc<CV, true> {
     q.y = select_el((v & SIDX_NEG) != 0, ny, q.y);
     return q;
   }
+  // The same in two halves, for the software-pipelined gather of the level-1 loop: the raw words of the base
+  // record are requested one entry ahead and only turned into field elements (unpack, conditional negation) when
+  // the entry is consumed — any arithmetic on them at request time would make the wave wait for the data first.
+  struct Raw {
+    uint4 w[IO::AFF_WORDS / 4];
+  };
+  static __device__ __forceinline__ Raw load_raw(const u32* pts, u32 v) {
+    Raw r;
+    const uint4* p = reinterpret_cast<const uint4*>(pts + (size_t)(v & ~SIDX_NEG) * IO::AFF_WORDS);
+#pragma unroll
+    for (int k = 0; k < IO::AFF_WORDS / 4; k++) r.w[k] = p[k];
+    return r;
+  }
+  static __device__ __forceinline__ Aff<EA> decode(const Raw& r, u32 v) {
+    u32 w[IO::AFF_WORDS];
+#pragma unroll
+    for (int k = 0; k < IO::AFF_WORDS / 4; k++) {
+      w[4 * k] = r.w[k].x;
+      w[4 * k + 1] = r.w[k].y;
+      w[4 * k + 2] = r.w[k].z;
+      w[4 * k + 3] = r.w[k].w;
+    }
+    Aff<EA> q = IO::load_aff(w);
+    const EA ny = EA(reduce_to<17>(neg(q.y)));
+    q.y = select_el((v & SIDX_NEG) != 0, ny, q.y);
+    return q;
+  }
   __device__ __forceinline__ void start(const u32* pts, const u32* idx, long long p) {
     a = xyzz_from_affine<CV>(load_signed(pts, idx, p));
   }
@@ -789,6 +816,9 @@ struct RunAccLds {
   static __device__ __forceinline__ Aff<EA> load_signed(const u32* pts, const u32* idx, long long p) {
     return RunAcc<CV, true>::load_signed(pts, idx, p);
   }
+  using Raw = typename RunAcc<CV, true>::Raw;
+  static __device__ __forceinline__ Raw load_raw(const u32* pts, u32 v) { return RunAcc<CV, true>::load_raw(pts, v); }
+  static __device__ __forceinline__ Aff<EA> decode(const Raw& r, u32 v) { return RunAcc<CV, true>::decode(r, v); }
   __device__ __forceinline__ void start(const u32* pts, const u32* idx, long long p) {
     start_q(load_signed(pts, idx, p));
   }
@@ -893,18 +923,24 @@ segreduce_lane(const int t, const u32* __restrict__ bid_in, const u32* __restric
       acc.init(ozk_acc_lds);
     }
     if constexpr (FIRST) {
-      // level 1: the next entry's (bucket id, base) gather is issued one addition ahead,
-      // so the dependent idx -> base load chain overlaps the ~12 multiplications of the current one
+      // level 1, software-pipelined gather: while entry p is added, the base record of entry p + 1 (its index
+      // word is already here) and the index word of entry p + 2 are in flight; nothing is computed on them
+      // until they are consumed, so the dependent idx -> base chain never stalls the additions
       // (every entry of the sorted array is a live base index at this level)
-      u32 nb = first_bid;
-      auto nq = Acc::load_signed(pts_in, idx_in, s);
+      u32 v_cur = idx_in[s];
+      u32 v_next = (s + 1 < e) ? idx_in[s + 1] : 0u;
+      typename Acc::Raw r_cur = Acc::load_raw(pts_in, v_cur);
+      u32 b_cur = first_bid;
       for (long long p = s; p < e; p++) {
-        const u32 b = nb;
-        const auto q = nq;
+        typename Acc::Raw r_next = r_cur;
+        u32 b_next = BID_NONE, v_next2 = 0u;
         if (p + 1 < e) {
-          nb = bid_in[p + 1];
-          nq = Acc::load_signed(pts_in, idx_in, p + 1);
+          r_next = Acc::load_raw(pts_in, v_next);
+          b_next = bid_in[p + 1];
         }
+        if (p + 2 < e) v_next2 = idx_in[p + 2];
+        const u32 b = b_cur;
+        const auto q = Acc::decode(r_cur, v_cur);
         if (b != cur) {
           if (cur != BID_NONE) {
             if (cur_cb) {
@@ -920,6 +956,10 @@ segreduce_lane(const int t, const u32* __restrict__ bid_in, const u32* __restric
         } else {
           acc.accumulate_q(q);
         }
+        r_cur = r_next;
+        v_cur = v_next;
+        v_next = v_next2;
+        b_cur = b_next;
       }
     } else {
     for (long long p = s; p < e; p++) {
