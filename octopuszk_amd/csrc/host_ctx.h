@@ -21,11 +21,14 @@ namespace ozk {
 
 constexpr size_t STAGE_BYTES = (size_t)16 << 20;
 constexpr int STAGE_RING = 3;
+constexpr int MAX_SLICES = 16;
 
 struct HostCtx {
   int device = -1;
-  hipStream_t st[2] = {nullptr, nullptr};  // [0] compute (+ its copies), [1] second engine (G2 / uploads)
+  hipStream_t st[3] = {nullptr, nullptr, nullptr};  // [0] compute (+ its copies), [1] second engine (G2 / odd slices),
+                                                    // [2] uploads that must not queue behind kernels
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t slice_ev[MAX_SLICES] = {};  // upload of slice s complete
   uint8_t* arena = nullptr;  // device, grow-only
   size_t arena_cap = 0;
   uint8_t* stage[STAGE_RING] = {nullptr, nullptr, nullptr};  // pinned host

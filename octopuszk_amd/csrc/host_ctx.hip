@@ -119,6 +119,8 @@ void ctx_destroy(HostCtx* c) {
     }
   for (auto& e : c->ev)
     if (e) hipEventDestroy(e);
+  for (auto& e : c->slice_ev)
+    if (e) hipEventDestroy(e);
   for (int i = 0; i < STAGE_RING; i++) {
     if (c->stage[i]) hipHostFree(c->stage[i]);
     if (c->stage_free[i]) hipEventDestroy(c->stage_free[i]);
@@ -146,6 +148,8 @@ int ctx_acquire(int task_id, HostCtx** out) {
       if (e == hipSuccess) e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
     for (auto& v : c->ev)
       if (e == hipSuccess) e = hipEventCreateWithFlags(&v, hipEventDisableTiming);
+    for (auto& v : c->slice_ev)
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&v, hipEventDisableTiming);
     for (int i = 0; i < STAGE_RING; i++) {
       if (e == hipSuccess) e = hipHostMalloc((void**)&c->stage[i], STAGE_BYTES, hipHostMallocDefault);
       if (e == hipSuccess) e = hipEventCreateWithFlags(&c->stage_free[i], hipEventDisableTiming);
@@ -172,8 +176,7 @@ void ctx_release(HostCtx* c) {
 int ctx_reserve(HostCtx* c, size_t bytes) {
   if (bytes <= c->arena_cap) return OZK_OK;
   // everything queued on this context's streams may still use the old arena
-  OZK_HIP(hipStreamSynchronize(c->st[0]));
-  OZK_HIP(hipStreamSynchronize(c->st[1]));
+  for (auto& s : c->st) OZK_HIP(hipStreamSynchronize(s));
   if (c->arena) OZK_HIP(hipFree(c->arena));
   c->arena = nullptr;
   c->arena_cap = 0;

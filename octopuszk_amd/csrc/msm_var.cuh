@@ -1225,6 +1225,34 @@ k_wsum_fused(const u32* __restrict__ buckets, const u32* __restrict__ hist, int 
   }
 }
 
+// ------------------------------------------------------------------ bucket arrays of several slices
+// The host entry point accumulates index-range slices of one MSM into separate bucket arrays (each slice's
+// kernels run while the next slice is still on its way over PCIe); this adds arrays 1 .. K-1 into array 0,
+// one lane per bucket, so that ONE latency-bound tail serves the whole call.
+struct SliceBuckets {
+  const u32* buckets[16];
+  const u32* hist[16];
+};
+template <class CV>
+__global__ void __launch_bounds__(256) k_bucket_combine(SliceBuckets t, int K, u32* __restrict__ buckets0,
+                                                        u32* __restrict__ hist0, size_t NB) {
+  using IO = CurveIO<CV>;
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= NB) return;
+  bool have = hist0[e] != 0, changed = false;
+  Jac<CV> acc = jac_infinity<CV>();
+  if (have) acc = IO::load_rec(buckets0 + e * IO::REC_WORDS);
+  for (int k = 1; k < K; k++) {
+    if (t.hist[k][e] == 0) continue;  // never written
+    acc = jac_add(acc, IO::load_rec(t.buckets[k] + e * IO::REC_WORDS));
+    changed = true;
+  }
+  if (changed) {
+    IO::store_rec_jac(acc, buckets0 + e * IO::REC_WORDS);
+    hist0[e] = 1;
+  }
+}
+
 // ------------------------------------------------------------------ finalize
 // affine-normalise and emit the reference's return layout: per Fq value 64 B LE, upper
 // 32 B zero (VariableBaseMSM.cu:1655-1659); infinity -> (0, 1, 0) (BNG1.java:163-172).

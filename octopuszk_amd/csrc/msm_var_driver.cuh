@@ -473,8 +473,29 @@ size_t var_msm_ws_bytes(int n) {
 // host-buffer variant (what the JNI native calls): staged upload, run, download, all on a cached context
 // (host_ctx.h) — no allocation, stream creation or pageable copy per call.  Re-entrant: concurrent callers
 // (Spark task threads in the reference, SURVEY.md §8b "Threading") each take their own context.
-// The scalars go up first so that the digit extraction and the first half of the sort input are ready while
-// the bases (3/4 of the bytes) are still on their way; the MSM itself needs everything.
+//
+// A large call is cut into index-range SLICES that share one set of windows and ONE tail: slice s is uploaded on
+// the context's copy stream and its sort + bucket accumulation (into its own bucket array) are queued behind that
+// upload before the host thread starts staging slice s + 1, so all but the last slice's throughput-bound work
+// runs under the PCIe transfer (128 MiB at 2^20 G1: ~2.9 ms of upload against ~1.9 ms of such work); then the
+// bucket arrays are added (k_bucket_combine) and the latency-bound tail runs once.  (Complete MSMs per slice,
+// summed at the end, measured SLOWER than no slicing beyond two slices: every slice pays the ~1.1 ms tail, and
+// they queue — profiles/r02_host_path.txt.)  All slices use the plan of the slice size; the last one is padded
+// with zero scalars / infinity bases.  Within a slice the scalars go up first.
+// Slice count: slices of at least 2^18 pairs (below that the head of an MSM stops shrinking with its size: a
+// 2^17 MSM takes as long as a 2^18 one, tools/host_slices_probe.py), at most OZK_HOST_SLICES (8).  Measured
+// ozk_var_msm_host at 2^20 G1: 6.0 ms unsliced, 4.8 ms in 4 slices; 2^22: 19.7 -> 12.8 ms in 8; G2 2^20: 13.6 -> 11.5.
+inline int host_slices(int n) {
+  int kmax = env_int("OZK_HOST_SLICES", 8);
+  if (kmax > MAX_SLICES) kmax = MAX_SLICES;
+  int min_log = env_int("OZK_HOST_SLICE_MIN_LOG", 18);  // (tests lower it to slice small inputs)
+  if (min_log < 4) min_log = 4;
+  if (min_log > 30) min_log = 30;
+  int k = n >> min_log;
+  if (k > kmax) k = kmax;
+  return k < 1 ? 1 : k;
+}
+
 template <class CV>
 int var_msm_host(const uint8_t* bases, const uint8_t* scalars, int n, int task_id, uint8_t* out) {
   using IO = CurveIO<CV>;
@@ -482,18 +503,60 @@ int var_msm_host(const uint8_t* bases, const uint8_t* scalars, int n, int task_i
   int rc = ctx_acquire(task_id, &g.c);
   if (rc) return rc;
   HostCtx* c = g.c;
-  const size_t base_bytes = (size_t)n * IO::WIRE_JAC_WORDS * 4, sc_bytes = (size_t)n * 32;
+  const size_t base_rec = (size_t)IO::WIRE_JAC_WORDS * 4;
   const size_t out_bytes = (size_t)IO::WIRE_JAC_WORDS * 8;
-  const size_t ws_bytes = var_msm_ws_bytes<CV>(n);
-  if ((rc = ctx_reserve(c, pad256(base_bytes) + pad256(sc_bytes) + 1024 + ws_bytes + 1024))) return rc;
+  const int K = host_slices(n);
+  if (K == 1) {
+    const size_t base_bytes = (size_t)n * base_rec, sc_bytes = (size_t)n * 32;
+    const size_t ws_bytes = var_msm_ws_bytes<CV>(n);
+    if ((rc = ctx_reserve(c, pad256(base_bytes) + pad256(sc_bytes) + 1024 + ws_bytes + 1024))) return rc;
+    uint8_t* d_bases = c->arena;
+    uint8_t* d_sc = d_bases + pad256(base_bytes);
+    uint8_t* d_out = d_sc + pad256(sc_bytes);
+    uint8_t* d_ws = d_out + 1024;
+    hipStream_t st = c->st[0];
+    if ((rc = staged_h2d(c, d_sc, scalars, sc_bytes, st))) return rc;
+    if ((rc = staged_h2d(c, d_bases, bases, base_bytes, st))) return rc;
+    if ((rc = var_msm_dev<CV>(d_bases, d_sc, n, d_out, d_ws, ws_bytes, st))) return rc;
+    return staged_d2h(c, out, d_out, out_bytes, st);
+  }
+  const int per = (n + K - 1) / K;               // every slice is planned and laid out for `per` pairs
+  const size_t padded = (size_t)K * per;
+  const size_t main_bytes = pad256(var_msm_head_ws_bytes<CV>(per));
+  const size_t tb = pad256(var_msm_tail_bytes<CV>(per));
+  if ((rc = ctx_reserve(c, pad256(padded * base_rec) + pad256(padded * 32) + 1024 + main_bytes + (size_t)K * tb + 1024)))
+    return rc;
   uint8_t* d_bases = c->arena;
-  uint8_t* d_sc = d_bases + pad256(base_bytes);
-  uint8_t* d_out = d_sc + pad256(sc_bytes);
+  uint8_t* d_sc = d_bases + pad256(padded * base_rec);
+  uint8_t* d_out = d_sc + pad256(padded * 32);
   uint8_t* d_ws = d_out + 1024;
-  hipStream_t st = c->st[0];
-  if ((rc = staged_h2d(c, d_sc, scalars, sc_bytes, st))) return rc;
-  if ((rc = staged_h2d(c, d_bases, bases, base_bytes, st))) return rc;
-  if ((rc = var_msm_dev<CV>(d_bases, d_sc, n, d_out, d_ws, ws_bytes, st))) return rc;
+  uint8_t* d_tails = d_ws + main_bytes;
+  hipStream_t st = c->st[0], up = c->st[2];  // uploads on their own queue: they must not wait behind kernels
+  if (padded > (size_t)n) {
+    OZK_HIP(hipMemsetAsync(d_sc + (size_t)n * 32, 0, (padded - n) * 32, up));
+    OZK_HIP(hipMemsetAsync(d_bases + (size_t)n * base_rec, 0, (padded - n) * base_rec, up));  // Z = 0: infinity
+  }
+  const MsmPlan p = make_plan(per);
+  SliceBuckets sb = {};
+  for (int s = 0; s < K; s++) {
+    const size_t lo = (size_t)s * per;
+    const size_t ns = ((size_t)n - lo < (size_t)per) ? ((size_t)n - lo) : (size_t)per;
+    if ((rc = staged_h2d(c, d_sc + lo * 32, scalars + lo * 32, ns * 32, up))) return rc;
+    if ((rc = staged_h2d(c, d_bases + lo * base_rec, bases + lo * base_rec, ns * base_rec, up))) return rc;
+    OZK_HIP(hipEventRecord(c->slice_ev[s], up));
+    OZK_HIP(hipStreamWaitEvent(st, c->slice_ev[s], 0));
+    uint8_t* tail = d_tails + (size_t)s * tb;
+    if ((rc = var_msm_head<CV>(d_bases + lo * base_rec, d_sc + lo * 32, per, d_ws, main_bytes, tail, tb, st))) return rc;
+    MsmLayout L;
+    tail_layout<CV>(p, L, tail, tb);
+    sb.buckets[s] = L.buckets;
+    sb.hist[s] = L.hist_t;
+  }
+  const size_t NB = (size_t)p.W << p.cb;
+  hipLaunchKernelGGL((k_bucket_combine<CV>), dim3((unsigned)((NB + 255) / 256)), dim3(256), 0, st, sb, K,
+                     (u32*)sb.buckets[0], (u32*)sb.hist[0], NB);
+  OZK_HIP(hipGetLastError());
+  if ((rc = var_msm_tail<CV>(per, d_tails, tb, d_out, st))) return rc;
   return staged_d2h(c, out, d_out, out_bytes, st);
 }
 

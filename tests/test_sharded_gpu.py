@@ -137,3 +137,42 @@ def test_in_process_sharded_entry_equals_single_call(type_, n, shards):
         assert bytes(got) == (o.g1_out_le(want) if type_ == 1 else o.g2_out_le(want))
     elif type_ == 1:
         assert bytes(got) == coracle.pippenger_g1(bw.tobytes(), sc.tobytes(), n)
+
+
+@pytest.mark.parametrize("type_,n,min_log", [(1, (1 << 19) + 37, 18), (1, 70001, 14), (2, 9001, 11), (1, 4099, 12)])
+def test_host_entry_sliced_upload_equals_single_slice(type_, n, min_log, monkeypatch):
+    """ozk_var_msm_host cuts a large call into index-range slices (each sorted and accumulated into its own bucket
+    array behind its own upload; the arrays are added and ONE tail finishes): the bytes must be those of the
+    unsliced call, and for G1 the C oracle's over the whole input.  Repeated bases, so that the same point meets
+    itself when bucket arrays are added; the last slice is padded."""
+    import ctypes
+    from octopuszk_amd import lib
+    L = lib.load()
+    rng = np.random.default_rng(n)
+    G = o.G1 if type_ == 1 else o.G2
+    to_wire = o.g1_to_wire if type_ == 1 else o.g2_to_wire
+    pts = [G.to_affine(G.mul(G.one, int(k))) for k in rng.integers(1, 1 << 62, size=32)]
+    pts[5] = G.zero
+    wire = [np.frombuffer(to_wire(p), dtype=np.uint8) for p in pts]
+    bw = np.ascontiguousarray(np.stack(wire)[rng.integers(0, 32, size=n)]).reshape(-1)
+    sc = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    sc[:, 31] &= 0x1F
+    sc[: n // 3, 2:] = 0          # a third of the scalars tiny: whole windows of some slices stay empty
+    ob = 192 if type_ == 1 else 384
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    outs = {}
+    try:
+        monkeypatch.setenv("OZK_HOST_SLICE_MIN_LOG", str(min_log))
+        for k in (8, 1, 3):
+            monkeypatch.setenv("OZK_HOST_SLICES", str(k))
+            lib.check(L.ozk_tuning_reload())
+            got = np.zeros(ob, dtype=np.uint8)
+            lib.check(L.ozk_var_msm_host(vp(bw), vp(sc), n, type_, 0, vp(got)))
+            outs[k] = bytes(got)
+    finally:
+        monkeypatch.delenv("OZK_HOST_SLICES", raising=False)
+        monkeypatch.delenv("OZK_HOST_SLICE_MIN_LOG", raising=False)
+        lib.check(L.ozk_tuning_reload())
+    assert outs[8] == outs[1] == outs[3]
+    if type_ == 1:
+        assert outs[8] == coracle.pippenger_g1(bw.tobytes(), sc.tobytes(), n)
