@@ -1341,6 +1341,7 @@ __global__ void __launch_bounds__(64) k_points_sum(const u32* __restrict__ pts, 
   using ET = ElemTraits<EA>;
   constexpr int OW = 2 * ET::WORDS;
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  __builtin_amdgcn_s_setprio(3);  // one lane of one wave, usually beside another MSM's accumulation kernel
   pts += opaque_zero();
   Jac<CV> r = jac_infinity<CV>();
   for (int i = 0; i < k; i++) {

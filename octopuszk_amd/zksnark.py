@@ -498,33 +498,31 @@ class SerialProver:
             _lib.check(L.ozk_var_msm_prepare_dev(_ptr(d_bases), n, type_, _ptr(out), nb, _stream()))
             return out
 
-        # A = alpha + sum z_i A_i(t) + r delta (SerialProver.java:105) = primary MSM + an auxiliary MSM whose
-        # base array carries alphaG1 and deltaG1 behind the auxiliary slice of query A (scalars 1 and r);
-        # B likewise with beta, delta and s (:108-110).  Same group elements, two scalar multiplications and
-        # four additions fewer on the critical path.
+        # A = alpha + sum z_i A_i(t) + r delta (SerialProver.java:76-79,105): the Java sums a primary-input MSM,
+        # an auxiliary-input MSM, alpha and r delta; here ONE MSM over query A ++ [alphaG1, deltaG1] with scalars
+        # z ++ [1, r] — the same group element, hence the same affine bytes, without the two short MSMs (each of
+        # which costs a whole latency-bound tail) and four additions.  B likewise with beta, delta and s (:82-88,108-110).
         cat = torch.cat
-        self.qa_p = prep(pk.query_a[:ni * 96].contiguous(), ni, 1)
-        self.qa_w = prep(cat((pk.query_a[ni * 96:], pk.alpha_g1, pk.delta_g1)), nw + 2, 1)
-        self.qb1_p = prep(pk.query_b_g1[:ni * 96].contiguous(), ni, 1)
-        self.qb1_w = prep(cat((pk.query_b_g1[ni * 96:], pk.beta_g1, pk.delta_g1)), nw + 2, 1)
-        self.qb2_p = prep(pk.query_b_g2[:ni * 192].contiguous(), ni, 2)
-        self.qb2_w = prep(cat((pk.query_b_g2[ni * 192:], pk.beta_g2, pk.delta_g2)), nw + 2, 2)
+        self.qa = prep(cat((pk.query_a, pk.alpha_g1, pk.delta_g1)), self.nv + 2, 1)
+        self.qb1 = prep(cat((pk.query_b_g1, pk.beta_g1, pk.delta_g1)), self.nv + 2, 1)
+        self.qb2 = prep(cat((pk.query_b_g2, pk.beta_g2, pk.delta_g2)), self.nv + 2, 2)
         self.qh = prep(pk.query_h, m + 1, 1)
         self.dabc = prep(pk.delta_abc_g1, nw, 1)
         torch.cuda.synchronize()
-        self.pipe = _G1Pipeline([ni, nw + 2, m + 1, nw])
-        self.g2_ws_bytes = max(int(L.ozk_var_msm_workspace_bytes(n, 2)) for n in (ni, nw + 2))
+        self.pipe = _G1Pipeline([self.nv + 2, m + 1, nw])
+        self.g2_ws_bytes = int(L.ozk_var_msm_workspace_bytes(self.nv + 2, 2))
         self.g2_ws = torch.empty(self.g2_ws_bytes, dtype=torch.uint8, device="cuda")
         self.s_g2 = torch.cuda.Stream()
-        self.s_fin = torch.cuda.Stream()
+        # witness map + C's share: dispatched ahead of the MSMs that do not depend on them (the H MSM waits for the map)
+        self.s_fin = torch.cuda.Stream(priority=-1)
         self.fin_ws_bytes = int(L.ozk_var_msm_workspace_bytes(3, 1))
         self.fin_ws = torch.empty(self.fin_ws_bytes, dtype=torch.uint8, device="cuda")
         self.q_ws_bytes = int(L.ozk_qap_witness_workspace_bytes(m))
         self.q_ws = torch.empty(self.q_ws_bytes, dtype=torch.uint8, device="cuda")
         self.d_h = torch.empty((m + 1) * 32, dtype=torch.uint8, device="cuda")
         # results: G1 MSM outputs (192 B each) and G2 outputs (384 B)
-        self.o1 = torch.zeros(9, 192, dtype=torch.uint8, device="cuda")
-        self.o2 = torch.zeros(3, 384, dtype=torch.uint8, device="cuda")
+        self.o1 = torch.zeros(5, 192, dtype=torch.uint8, device="cuda")   # A, B1, deltaABC, H, C's share
+        self.o2 = torch.zeros(1, 384, dtype=torch.uint8, device="cuda")   # B
         self.r1cs_dev = R1CSDevice(r1cs)   # the constraint matrices, uploaded once per key
         self.omega = ctypes.create_string_buffer(root_of_unity(m).to_bytes(32, "little"), 32)
         self.g = ctypes.create_string_buffer(FR_MULT_GEN.to_bytes(32, "little"), 32)
@@ -547,11 +545,11 @@ class SerialProver:
         s = fr_random(seed)
         t1 = time.perf_counter()
         d_full = torch.from_numpy(full_bytes).cuda()
-        tails = _dev_bytes(_le32([1, r, 1, s, 1, 1, s, r, (FR - r * s % FR) % FR]))
-        d_prim, d_aux = d_full[:ni * 32], d_full[ni * 32:]
-        d_aux_r = torch.cat((d_aux, tails[:64]))                 # auxiliary ++ [1, r]
-        d_aux_s = torch.cat((d_aux, tails[64:128]))              # auxiliary ++ [1, s]
-        d_fin_sc = tails[192:]                                   # [s, r, -rs]
+        tails = _dev_bytes(_le32([1, r, 1, s, s, r, (FR - r * s % FR) % FR]))
+        d_aux = d_full[ni * 32:]
+        d_full_r = torch.cat((d_full, tails[:64]))               # z ++ [1, r]
+        d_full_s = torch.cat((d_full, tails[64:128]))            # z ++ [1, s]
+        d_fin_sc = tails[128:]                                   # [s, r, -rs]
         torch.cuda.synchronize()
         T["upload_ms"] = (time.perf_counter() - t1) * 1e3
         t2 = time.perf_counter()
@@ -559,56 +557,54 @@ class SerialProver:
         ready = torch.cuda.Event()
         ready.record(main)
         o1, o2 = self.o1, self.o2
-        # B in G2 (doubleMSM, SerialProver.java:82-88): own stream, nothing to wait for but the uploads
+        nv = self.nv
+        # B in G2 (doubleMSM, SerialProver.java:82-88): own stream, nothing to wait for but the uploads.  Issued
+        # first: its tail is the longest latency-bound chain of the proof and hides under the G1 accumulations.
         self.s_g2.wait_event(ready)
         with torch.cuda.stream(self.s_g2):
-            st2 = _stream()
-            _lib.check(L.ozk_var_msm_prepared_dev(_ptr(self.qb2_p), _ptr(d_prim), ni, 2, _ptr(o2[0]), _ptr(self.g2_ws),
-                                                  self.g2_ws_bytes, st2))
-            _lib.check(L.ozk_var_msm_prepared_dev(_ptr(self.qb2_w), _ptr(d_aux_s), nw + 2, 2, _ptr(o2[1]),
-                                                  _ptr(self.g2_ws), self.g2_ws_bytes, st2))
-            _lib.check(L.ozk_points_sum_dev(_ptr(o2[:2]), 2, 2, _ptr(o2[2]), st2))   # B = primary + (aux + beta + s delta)
+            _lib.check(L.ozk_var_msm_prepared_dev(_ptr(self.qb2), _ptr(d_full_s), nv + 2, 2, _ptr(o2[0]), _ptr(self.g2_ws),
+                                                  self.g2_ws_bytes, _stream()))
             g2_done = torch.cuda.Event()
             g2_done.record(self.s_g2)
         # witness map (SerialProver.java:36-41): constraint evaluations (R1CStoQAP.java:143-160,195-199) and the
-        # seven transforms on the device; coefficientsH stay in HBM
-        d_ev = self.r1cs_dev.evaluate(d_full)
-        _lib.check(L.ozk_qap_witness_dev(_ptr(d_ev[0]), _ptr(d_ev[1]), _ptr(d_ev[2]), m, ctypes.cast(self.omega, ctypes.c_void_p),
-                                         ctypes.cast(self.g, ctypes.c_void_p), _ptr(self.d_h), _ptr(self.q_ws),
-                                         self.q_ws_bytes, int(main.cuda_stream)))
-        p = self.pipe
-        evs = [p.submit(self.qa_p, d_prim, ni, o1[0]),           # :76-79 query A
-               p.submit(self.qa_w, d_aux_r, nw + 2, o1[1]),
-               p.submit(self.qb1_p, d_prim, ni, o1[2]),          # :82-88 query B, G1 half
-               p.submit(self.qb1_w, d_aux_s, nw + 2, o1[3])]
-        # A and B1 are complete once those four tails are: their share of C — s A + r B1 - r s delta (:114) —
-        # is a 3-term MSM that runs on its own stream while the two long MSMs (H, deltaABC) still occupy the pipeline
+        # seven transforms on the device; coefficientsH stay in HBM.  Own stream: only the H MSM waits for it, the
+        # three MSMs over the assignment run beside it.
+        self.s_fin.wait_event(ready)
         with torch.cuda.stream(self.s_fin):
-            for e in evs:
-                self.s_fin.wait_event(e)
-            sf = _stream()
-            _lib.check(L.ozk_points_sum_dev(_ptr(o1[0:2]), 2, 1, _ptr(o1[6]), sf))       # A
-            _lib.check(L.ozk_points_sum_dev(_ptr(o1[2:4]), 2, 1, _ptr(o1[7]), sf))       # B in G1
-            fin_bases = torch.cat((wire_out_to_in(o1[6], 1), wire_out_to_in(o1[7], 1), pk.delta_g1))
-            _lib.check(L.ozk_var_msm_dev(_ptr(fin_bases), _ptr(d_fin_sc), 3, 1, _ptr(o1[8]), _ptr(self.fin_ws),
-                                         self.fin_ws_bytes, sf))
+            d_ev = self.r1cs_dev.evaluate(d_full)
+            _lib.check(L.ozk_qap_witness_dev(_ptr(d_ev[0]), _ptr(d_ev[1]), _ptr(d_ev[2]), m, ctypes.cast(self.omega, ctypes.c_void_p),
+                                             ctypes.cast(self.g, ctypes.c_void_p), _ptr(self.d_h), _ptr(self.q_ws),
+                                             self.q_ws_bytes, _stream()))
+            h_ready = torch.cuda.Event()
+            h_ready.record(self.s_fin)
+        p = self.pipe
+        ev_a = p.submit(self.qa, d_full_r, nv + 2, o1[0])        # :76-79,105  A
+        ev_b = p.submit(self.qb1, d_full_s, nv + 2, o1[1])       # :82-88,108-110  B in G1
+        # A and B1 are complete once their tails are: their share of C — s A + r B1 - r s delta (:114) — is a 3-term
+        # MSM that runs on its own stream while the long MSMs still occupy the pipeline.  (The waits are queued NOW:
+        # the pipeline re-records these per-slot events for the next two submissions.)
+        self.s_fin.wait_event(ev_a)
+        self.s_fin.wait_event(ev_b)
+        ev_l = p.submit(self.dabc, d_aux, nw, o1[2])             # :98-101 deltaABC
+        main.wait_event(h_ready)
+        ev_h = p.submit(self.qh, self.d_h, m + 1, o1[3])         # :91-93 query H
+        with torch.cuda.stream(self.s_fin):
+            fin_bases = torch.cat((wire_out_to_in(o1[0], 1), wire_out_to_in(o1[1], 1), pk.delta_g1))
+            _lib.check(L.ozk_var_msm_dev(_ptr(fin_bases), _ptr(d_fin_sc), 3, 1, _ptr(o1[4]), _ptr(self.fin_ws),
+                                         self.fin_ws_bytes, _stream()))
             fin_done = torch.cuda.Event()
             fin_done.record(self.s_fin)
-        evs2 = [p.submit(self.qh, self.d_h, m + 1, o1[4]),       # :91-93 query H
-                p.submit(self.dabc, d_aux, nw, o1[5])]           # :98-101 deltaABC
-        for e in evs2:
-            main.wait_event(e)
+        main.wait_event(ev_l)
+        main.wait_event(ev_h)
         main.wait_event(fin_done)
-        st = int(main.cuda_stream)
         # C = evaluationABC + H(t)Z(t)/delta + (s A + r B1 - r s delta)   (:102,:114)
-        c_in = torch.cat((o1[5], o1[4], o1[8]))
         c_out = torch.zeros(192, dtype=torch.uint8, device="cuda")
-        _lib.check(L.ozk_points_sum_dev(_ptr(c_in), 3, 1, _ptr(c_out), st))
+        _lib.check(L.ozk_points_sum_dev(_ptr(o1[2:5]), 3, 1, _ptr(c_out), int(main.cuda_stream)))
         main.wait_event(g2_done)
         torch.cuda.synchronize()
         T["gpu_ms"] = (time.perf_counter() - t2) * 1e3
-        proof = Proof(bytes(o1[6].cpu().numpy()), bytes(o2[2].cpu().numpy()), bytes(c_out.cpu().numpy()))
-        self._keep = (d_full, tails, d_aux_r, d_aux_s, fin_bases, c_in)
+        proof = Proof(bytes(o1[0].cpu().numpy()), bytes(o2[0].cpu().numpy()), bytes(c_out.cpu().numpy()))
+        self._keep = (d_full, tails, d_full_r, d_full_s, fin_bases, d_ev)
         if timing is not None:
             timing.update(T)
         return proof
