@@ -117,12 +117,13 @@ int ozk_var_msm_head_prepared_dev(const void* d_prepared, const void* d_scalars,
                                   void* d_workspace, size_t workspace_bytes, void* d_tail, size_t tail_bytes,
                                   void* stream, void* previous_levels_done);
 
-/* Ordering hint for several MSMs in flight on two streams.  The bucket accumulation of MSM k+1 fills
- * every SIMD's register file; if it is dispatched before the single-wave Horner kernel of MSM k is
- * resident, that kernel waits for a free slot (+0.7 ms) and then starves the accumulation blocks next
- * to it (measured: 447 -> 370 Mscalar-mul/s).  `tail_ordered` records `levels_done` after its multi-wave
- * window-sum levels, right before the Horner kernel; `head_ordered` waits for it after its sort and
- * before its accumulation.  Events come from ozk_order_event_create (a HIP event underneath). */
+/* Ordering hint for several MSMs in flight on two streams.  `tail_ordered` records `levels_done` after its first
+ * window-sum level (after the last multi-wave level with OZK_MSM_ORDER_EARLY=0, round 1's form); `head_ordered`
+ * waits for it after its sort and before its bucket accumulation, so that the previous MSM's wave-cooperative
+ * level is resident before the accumulation takes three of the four wave slots of every SIMD.  Measured at 2^20:
+ * 576 Mscalar-mul/s (538 with the late event; 576 with no event at all — the hint no longer buys throughput
+ * since the accumulation kernel leaves a slot free, it only keeps the order deterministic).
+ * Events come from ozk_order_event_create (a HIP event underneath). */
 int ozk_order_event_create(void** ev);
 int ozk_order_event_destroy(void* ev);
 int ozk_var_msm_head_ordered_dev(const void* d_bases, const void* d_scalars, int32_t n, int32_t type,
@@ -136,8 +137,9 @@ int ozk_var_msm_tail_ordered_dev(int32_t n, int32_t type, void* d_tail, size_t t
  * vector ALU) — so a caller may pipeline three stages (sort of MSM k+2 | accumulate of k+1 |
  * tail of k).  The hand-off between them is the "sorted set" (double-buffer it); sort and
  * accumulate each have private scratch.  ozk_var_msm_head_dev == sort + accumulate.  (On
- * MI355X the two-stage head | tail pipeline measured faster — 398 vs 348 Mscalar-mul/s at 2^20 —
- * because the sort's LDS traffic slows the co-running accumulation more than it hides.) */
+ * MI355X the three-stage form measures 562-574 Mscalar-mul/s at 2^20 against 576 for head | tail: the
+ * sort kernels cannot co-reside with three accumulation blocks per CU and stretch the accumulation
+ * when they can — profiles/r02_schedule_experiments.txt.) */
 int ozk_var_msm_stage_bytes(int32_t n, int32_t type, size_t* sorted_bytes, size_t* sort_ws_bytes,
                             size_t* accum_ws_bytes);
 int ozk_var_msm_sort_dev(const void* d_bases, const void* d_scalars, int32_t n, int32_t type,

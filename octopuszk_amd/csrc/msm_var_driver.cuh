@@ -413,12 +413,14 @@ int var_msm_tail(int n, void* tail, size_t tail_bytes, void* d_out, hipStream_t 
   int fin_max = env_int("OZK_MSM_FIN_MAX", 4);
   if (fin_max < 1) fin_max = 1;
   if (fin_max > 16) fin_max = 16;
-  // OZK_MSM_ORDER_EARLY=1 records the order event after the FIRST window-sum level instead; with
-  // OZK_MSM_S=8 the wave level behind it is 8 waves, which find a free slot beside the next accumulation
-  // (it keeps one per SIMD free).  Measured against the default (S = 4, event after the wave level): the
-  // same throughput (481-489 vs 475-485 Mscalar-mul/s), a shorter single MSM (3.30 vs 3.43 ms), but the
-  // accumulation kernel itself stretched from 1.40 to 1.50 ms by the overlap — not the default.
-  const bool order_early = env_int("OZK_MSM_ORDER_EARLY", 0) != 0;
+  // Launch-order hint for pipelined MSMs: the event fires here, after the FIRST window-sum level, so that the next
+  // accumulation starts as soon as its sort is done and the wave level behind this point is already resident.
+  // Round 1 recorded it after the wave level (OZK_MSM_ORDER_EARLY=0), when the accumulation kernel filled every
+  // register file; since that kernel is capped at 3 blocks per CU the late event only delays the next
+  // accumulation by ~0.18 ms per MSM: measured 538 (late) against 576 Mscalar-mul/s (early, or no hint at all).
+  // Also measured and not shipped (profiles/r02_schedule_experiments.txt): the merge of the level-1 pieces moved
+  // from the head to the tail stream (524-550), a three-stage schedule sort | accumulate | tail (562-599).
+  const bool order_early = env_int("OZK_MSM_ORDER_EARLY", 1) != 0;
   if (order_ev && order_early) OZK_HIP(hipEventRecord(order_ev, st));
   while (m_in > fin_max) {
     const int m_out = (m_in + 63) / 64;
