@@ -282,11 +282,12 @@ def main():
                     "kernel_avg_ms": round(k_ms, 4), "launches_timed": launches.value,
                     "algorithmic_bytes_per_launch": alg_bytes,
                     # the bound that actually holds: v_mad_u64_u32 issue.  10 Montgomery
-                    # multiplications per XYZZ mixed addition x points x windows, against the 172 G mulmod/s
-                    # this chip sustains on back-to-back multiplications (profiles/r01_ubench.txt)
+                    # multiplications per XYZZ mixed addition x points x windows, against the 179 G mulmod/s
+                    # this chip sustains on back-to-back multiplications in the shipped form (per-column
+                    # v_mad_u64_u32 chains, 8 waves per SIMD: profiles/r02_ubench_mont.txt, variant E)
                     "alu": {"achieved": round(10.0 * adds / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else 0.0,
-                            "peak": 172.0, "unit": "G mulmod/s",
-                            "frac": round(10.0 * adds / (k_ms * 1e-3) / 1e9 / 172.0, 3) if k_ms > 0 else 0.0},
+                            "peak": 179.0, "unit": "G mulmod/s",
+                            "frac": round(10.0 * adds / (k_ms * 1e-3) / 1e9 / 179.0, 3) if k_ms > 0 else 0.0},
                     "note": "integer-ALU-bound: 10 Fq mulmod per XYZZ mixed add x %d points x %d windows%s; see DESIGN.md"
                             % (n * (2 if glv else 1), wn.value, " (GLV: 2n half-length scalars)" if glv else "")}
         cpu = None
