@@ -47,8 +47,20 @@ static MsmPlan make_plan(int n) {
   int c = 4;
   double best = 1e300;
   for (int k = 4; k <= 16; k++) {
-    const double W = (double)((bits + k - 1) / k);
-    const double cost = (double)p.n * W + 3.4 * W * (double)(1u << (k - sd_ok));
+    const int Wk = (bits + k - 1) / k;
+    const double W = (double)Wk;
+    double cost = (double)p.n * W + 3.4 * W * (double)(1u << (k - sd_ok));
+    if (p.glv) {
+      // half scalars have ~127 bits: the top window's digits span top_bits, so its buckets hold 2^(k - top_bits)
+      // times the average; once such a bucket is cut into more pieces than the run merge takes (RUN_MAX) the
+      // generic levels wake up: +0.3 ms, about 4 M bucket additions' worth (2^17 with c = 13: 1.72 ms, the top
+      // window's buckets in 13 pieces; 1.5 ms with c = 16)
+      const int top_bits = 127 - (Wk - 1) * k;
+      const long long per_top = top_bits >= 1 ? ((long long)p.n >> (top_bits - sd_ok > 0 ? top_bits - sd_ok : 0)) : (long long)p.n;
+      long long l1 = ((long long)p.n >> (k - sd_ok)) * 5 / 16;
+      if (l1 < 40) l1 = 40;
+      if (per_top / l1 > 10) cost += 4.0e6;
+    }
     if (cost < best) {
       best = cost;
       c = k;
