@@ -49,6 +49,11 @@ int ctx_reserve(HostCtx* c, size_t bytes);
 int staged_h2d(HostCtx* c, void* d_dst, const void* h_src, size_t bytes, hipStream_t st);
 // device -> pageable host, staged; synchronises `st` (the data is in h_dst on return)
 int staged_d2h(HostCtx* c, void* h_dst, const void* d_src, size_t bytes, hipStream_t st);
+// the same for a buffer that is still being produced: before the copy of bytes [.., end) is queued, gate(arg, end)
+// must make `st` wait for their producer (hipStreamWaitEvent) — the download of the first ranges of a result
+// overlaps the computation of the later ones
+int staged_d2h_gated(HostCtx* c, void* h_dst, const void* d_src, size_t bytes, hipStream_t st,
+                     int (*gate)(void*, size_t), void* gate_arg);
 
 struct CtxGuard {  // release on scope exit
   HostCtx* c = nullptr;

@@ -213,7 +213,16 @@ int staged_h2d(HostCtx* c, void* d_dst, const void* h_src, size_t bytes, hipStre
 }
 
 int staged_d2h(HostCtx* c, void* h_dst, const void* d_src, size_t bytes, hipStream_t st) {
+  return staged_d2h_gated(c, h_dst, d_src, bytes, st, nullptr, nullptr);
+}
+
+int staged_d2h_gated(HostCtx* c, void* h_dst, const void* d_src, size_t bytes, hipStream_t st,
+                     int (*gate)(void*, size_t), void* gate_arg) {
   if (bytes <= ((size_t)1 << 16)) {  // a result point: one small synchronous copy
+    if (gate) {
+      int rc = gate(gate_arg, bytes);
+      if (rc) return rc;
+    }
     OZK_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, st));
     OZK_HIP(hipStreamSynchronize(st));
     return OZK_OK;
@@ -227,6 +236,10 @@ int staged_d2h(HostCtx* c, void* h_dst, const void* d_src, size_t bytes, hipStre
     if (rc) return rc;
     const size_t off = k * STAGE_BYTES;
     const size_t len = (bytes - off < STAGE_BYTES) ? (bytes - off) : STAGE_BYTES;
+    if (gate) {  // the producer of bytes [0, off + len) must have been ordered before this copy
+      rc = gate(gate_arg, off + len);
+      if (rc) return rc;
+    }
     OZK_HIP(hipMemcpyAsync(c->stage[b], (const uint8_t*)d_src + off, len, hipMemcpyDeviceToHost, st));
     OZK_HIP(hipEventRecord(c->stage_free[b], st));
     c->stage_busy[b] = true;

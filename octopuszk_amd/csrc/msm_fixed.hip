@@ -357,9 +357,15 @@ static int fb_check_args(int outerc, int ws, int n) {
   return OZK_OK;
 }
 
+// The table of a call (fb_table: doubling chain, level launches, affine copy) and the per-scalar part over any
+// sub-range of the scalars (fb_apply: gather-add + batched normalisation) are separate steps, so that the host
+// entry point can download the results of one range while the next is computed.
+struct FbPlan {
+  bool glv, affine;
+  int wt, oc;   // table window size / windows actually used
+};
 template <class CV>
-static int fixed_batch_dev(int outerc, int ws, int n, const void* d_base, const void* d_scalars, void* d_out,
-                           int out_stride_words, void* wsp, size_t wsb, hipStream_t st, int compact = 0) {
+static int fb_table(int outerc, int ws, int n, const void* d_base, void* wsp, size_t wsb, hipStream_t st, FbPlan* plan) {
   using IO = CurveIO<CV>;
   const FbLayout L = fb_layout<CV>(outerc, ws, n, wsp, wsb);
   if (L.bytes > wsb) return fail(OZK_E_INVALID, "workspace too small: need %zu bytes, got %zu", L.bytes, wsb);
@@ -391,27 +397,54 @@ static int fixed_batch_dev(int outerc, int ws, int n, const void* d_base, const 
     const int tot = oc << k;
     hipLaunchKernelGGL((k_fb_level<CV>), dim3((tot + TB - 1) / TB), dim3(TB), 0, st, L.table, L.D, oc, wt, k);
   }
-  if (glv && env_int("OZK_FB_AFFINE", 1) != 0) {
+  plan->glv = glv;
+  plan->affine = glv && env_int("OZK_FB_AFFINE", 1) != 0;
+  plan->wt = wt;
+  plan->oc = oc;
+  if (plan->affine) {
     const int entries = oc << wt;
     const int tl = (entries + FB_BATCH - 1) / FB_BATCH;
     hipLaunchKernelGGL((k_fb_table_affine<CV>), dim3((tl + TB - 1) / TB), dim3(TB), 0, st, L.table, entries, L.aff);
+  }
+  OZK_HIP(hipGetLastError());
+  return OZK_OK;
+}
+
+// scalars [lo, lo + cnt) of the call's n: d_scalars / d_out point at element 0
+template <class CV>
+static int fb_apply(const FbPlan& fp, int outerc, int ws, int n, int lo, int cnt, const void* d_scalars, void* d_out,
+                    int out_stride_words, void* wsp, size_t wsb, hipStream_t st, int compact) {
+  using IO = CurveIO<CV>;
+  const FbLayout L = fb_layout<CV>(outerc, ws, n, wsp, wsb);
+  const int TB = 256;
+  const u32* sc = (const u32*)d_scalars + (size_t)lo * 8;
+  u32* jac = L.jac + (size_t)lo * IO::JAC_WORDS;
+  if (fp.affine) {
     const size_t acc_lds = CV::LDS_ACC ? (size_t)RunAccLds<CV>::LDS_WORDS * TB * sizeof(u32) : 0;  // 72 KiB for G2
     if (acc_lds > 65536)
       OZK_HIP(hipFuncSetAttribute((const void*)(k_fb_main_glv_affine<CV>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)acc_lds));
-    hipLaunchKernelGGL((k_fb_main_glv_affine<CV>), dim3((n + TB - 1) / TB), dim3(TB), acc_lds, st,
-                       (const u32*)d_scalars, L.aff, n, oc, wt, L.jac);
-  } else if (glv)
-    hipLaunchKernelGGL((k_fb_main_glv<CV>), dim3((n + TB - 1) / TB), dim3(TB), 0, st, (const u32*)d_scalars, L.table,
-                       n, oc, wt, L.jac);
+    hipLaunchKernelGGL((k_fb_main_glv_affine<CV>), dim3((cnt + TB - 1) / TB), dim3(TB), acc_lds, st, sc, L.aff, cnt,
+                       fp.oc, fp.wt, jac);
+  } else if (fp.glv)
+    hipLaunchKernelGGL((k_fb_main_glv<CV>), dim3((cnt + TB - 1) / TB), dim3(TB), 0, st, sc, L.table, cnt, fp.oc, fp.wt,
+                       jac);
   else
-    hipLaunchKernelGGL((k_fb_main<CV>), dim3((n + TB - 1) / TB), dim3(TB), 0, st, (const u32*)d_scalars, L.table, n,
-                       outerc, ws, L.jac);
-  const int lanes = (n + FB_BATCH - 1) / FB_BATCH;
-  hipLaunchKernelGGL((k_fb_norm<CV>), dim3((lanes + TB - 1) / TB), dim3(TB), 0, st, L.jac, n, (u32*)d_out,
-                     out_stride_words, compact);
+    hipLaunchKernelGGL((k_fb_main<CV>), dim3((cnt + TB - 1) / TB), dim3(TB), 0, st, sc, L.table, cnt, outerc, ws, jac);
+  const int lanes = (cnt + FB_BATCH - 1) / FB_BATCH;
+  hipLaunchKernelGGL((k_fb_norm<CV>), dim3((lanes + TB - 1) / TB), dim3(TB), 0, st, jac, cnt,
+                     (u32*)d_out + (size_t)lo * out_stride_words, out_stride_words, compact);
   OZK_HIP(hipGetLastError());
   return OZK_OK;
+}
+
+template <class CV>
+static int fixed_batch_dev(int outerc, int ws, int n, const void* d_base, const void* d_scalars, void* d_out,
+                           int out_stride_words, void* wsp, size_t wsb, hipStream_t st, int compact = 0) {
+  FbPlan fp;
+  int rc = fb_table<CV>(outerc, ws, n, d_base, wsp, wsb, st, &fp);
+  if (rc) return rc;
+  return fb_apply<CV>(fp, outerc, ws, n, 0, n, d_scalars, d_out, out_stride_words, wsp, wsb, st, compact);
 }
 
 }  // namespace ozk
@@ -466,14 +499,49 @@ static int fixed_batch_host(int32_t outerc, int32_t ws, int32_t n, const uint8_t
   const size_t a0 = 256, a1 = a0 + pad256(sc_bytes), a2 = a1 + pad256(out_bytes);
   if ((rc = ctx_reserve(c, a2 + wsb + 256))) return rc;
   uint8_t* d = c->arena;
-  hipStream_t st = c->st[0];
+  hipStream_t st = c->st[0], cp = c->st[2];
   OZK_HIP(hipMemcpyAsync(d, base, base_bytes, hipMemcpyHostToDevice, st));
   OZK_HIP(hipStreamSynchronize(st));   // `base` is the caller's (pageable) memory
-  if ((rc = staged_h2d(c, d + a0, scalars, sc_bytes, st))) return rc;
-  rc = compact ? ozk_fixed_batch_msm_compact_dev(outerc, ws, n, d, d + a0, bn_type, d + a1, d + a2, wsb, st)
-               : ozk_fixed_batch_msm_dev(outerc, ws, n, d, d + a0, bn_type, d + a1, d + a2, wsb, st);
+  // The table (~1 ms at window 17, mostly the serial doubling chain) is built while the scalars are on their way;
+  // the per-scalar part then runs in ranges, each range's results going back to the host (on the copy stream,
+  // staged through the pinned ring) while the next ranges are computed: the output is 6 (compact: 3) times the
+  // input, so the call is bound by the download and nothing else should add to it.
+  const int osw = (g1 ? 48 : 96) / (compact ? 2 : 1);
+  FbPlan fp;
+  rc = g1 ? fb_table<G1Cfg>(outerc, ws, n, d, d + a2, wsb, st, &fp) : fb_table<G2Cfg>(outerc, ws, n, d, d + a2, wsb, st, &fp);
   if (rc) return rc;
-  return staged_d2h(c, out, d + a1, out_bytes, st);
+  if ((rc = staged_h2d(c, d + a0, scalars, sc_bytes, cp))) return rc;
+  OZK_HIP(hipEventRecord(c->ev[0], cp));
+  OZK_HIP(hipStreamWaitEvent(st, c->ev[0], 0));
+  // (4 ranges: 8 measured 0.2 ms faster at 2^20, but with occasional 10-30 ms calls that 4 never showed)
+  int K = env_int("OZK_FB_HOST_RANGES", 4);
+  if (K > MAX_SLICES) K = MAX_SLICES;
+  if (K > n / 4096) K = n / 4096;
+  if (K < 1) K = 1;
+  const int per = (((n + K - 1) / K) + 255) & ~255;
+  int ranges = 0;
+  for (int lo = 0; lo < n; lo += per, ranges++) {
+    const int cnt = n - lo < per ? n - lo : per;
+    rc = g1 ? fb_apply<G1Cfg>(fp, outerc, ws, n, lo, cnt, d + a0, d + a1, osw, d + a2, wsb, st, compact)
+            : fb_apply<G2Cfg>(fp, outerc, ws, n, lo, cnt, d + a0, d + a1, osw, d + a2, wsb, st, compact);
+    if (rc) return rc;
+    OZK_HIP(hipEventRecord(c->slice_ev[ranges], st));
+  }
+  // one continuous staged download; a piece is queued once the ranges it covers have been ordered before it
+  struct Gate {
+    HostCtx* c;
+    hipStream_t cp;
+    size_t range_bytes;
+    int ranges, waited;
+  } gate = {c, cp, (size_t)per * osw * 4, ranges, 0};
+  auto gate_fn = [](void* a, size_t end) -> int {
+    Gate* g = (Gate*)a;
+    int need = (int)((end + g->range_bytes - 1) / g->range_bytes);
+    if (need > g->ranges) need = g->ranges;
+    for (; g->waited < need; g->waited++) OZK_HIP(hipStreamWaitEvent(g->cp, g->c->slice_ev[g->waited], 0));
+    return OZK_OK;
+  };
+  return staged_d2h_gated(c, out, d + a1, out_bytes, cp, gate_fn, &gate);
 }
 
 int ozk_fixed_batch_msm_host(int32_t outerc, int32_t ws, int32_t out_len, int32_t inner_len, int32_t n,
