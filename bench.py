@@ -97,6 +97,9 @@ def main():
                          "24 over 8 GPUs = 2^21 per rank); the default is weak scaling, 2^LOGN pairs per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-streams-leg", action="store_true", help="skip the secondary three-streams throughput figure")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="nothing but warm-up + the timed steps (no single-MSM latency loop, no three-streams leg): the form "
+                         "profiled with rocprofv3, so that its per-kernel averages are those of the timed schedule")
     ap.add_argument("--prepared", action="store_true",
                     help="bases prepared once outside the timed region (ozk_var_msm_prepare_dev): NOT the "
                          "BASELINE.json workload, whose every MSM starts from the JNI wire bytes")
@@ -224,19 +227,19 @@ def main():
     ozk.check(L.ozk_prof_enable(0))
     # latency of ONE MSM with nothing else in flight (not part of `value`)
     lat = []
-    for _ in range(5):
+    for _ in range(0 if args.timed_only else 5):
         torch.cuda.synchronize()
         l0 = time.perf_counter()
         run_steps(1)
         torch.cuda.synchronize()
         lat.append(time.perf_counter() - l0)
-    single_ms = sorted(lat)[len(lat) // 2] * 1e3
+    single_ms = sorted(lat)[len(lat) // 2] * 1e3 if lat else 0.0
     # Secondary figure (never `value`): the same MSMs issued as three free-running streams — how concurrent
     # prover threads drive the library.  Higher throughput (everything but the bucket accumulation of one MSM runs
     # inside the accumulation of the others), but the co-running kernels stretch each accumulation launch, so the
     # default schedule, which keeps that kernel's duration clean for `roofline`, stays the timed one.
     streams3 = None
-    if world == 1 and args.schedule == "pipeline" and args.in_flight > 1 and not args.no_streams_leg:
+    if world == 1 and args.schedule == "pipeline" and args.in_flight > 1 and not (args.no_streams_leg or args.timed_only):
         ws3 = [dev.VarMsmWorkspace(n, 1) for _ in range(3)]
         # the runtime multiplexes streams onto 4 hardware queues (GPU_MAX_HW_QUEUES): two streams on one queue run
         # in order, so reuse the two streams this process already has rather than add three to them
