@@ -169,6 +169,33 @@ __device__ __forceinline__ void gstore(const PassArgs& a, int T, int logT, u32 m
   }
 }
 
+// a + b and a - b WITHOUT the carry pass (limbs may exceed 29 bits; BIAS limbs are < 2^30, a product's < 2^29).
+// Where a stage pair uses them, and why no limb overflows 32 bits and no product column 64:
+//   tile elements in LDS (the y outputs of a pair)   x < 1.5 x 2^30   (carried sum / difference +- a product)
+//   p, q = w1 * x01, w1 * x11                        one factor < 1.5 x 2^30, the twiddle normalised
+//   a0, a1 = x00 +- p                                CARRIED (the two values that are never multiplied in this pair)
+//   b0 = x10 + q < 2^31, b1 = x10 + BIAS - q < 2.5 x 2^30     uncarried; each is one factor of u, v = w2 * b:
+//                                                    9 (2.5 x 2^30 x 2^29 + 2^58) + carry < 1.7 x 2^63
+//   y = a +- u (to LDS)                              uncarried: < 2^29 + 2^30 = 1.5 x 2^30; carried when it leaves
+//                                                    the tile for global memory
+// The subtrahend is always a product (normalised).  Two carry passes per pair instead of eight: 0.59 -> 0.55 ms at 2^22.
+template <int B1, int B2>
+__device__ __forceinline__ Fe<FrP, B1 + B2> add_nc(const Fe<FrP, B1>& a, const Fe<FrP, B2>& b) {
+  Fe<FrP, B1 + B2> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + b.l[i];
+  return r;
+}
+template <int B1, int B2>
+__device__ __forceinline__ auto sub_nc(const Fe<FrP, B1>& a, const Fe<FrP, B2>& b) {
+  constexpr int K = B2 / 16 + 1;
+  static_assert(K <= FE_MAXK, "sub bias table too small");
+  Fe<FrP, B1 + 16 * K> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + (FrP::BIAS[K][i] - b.l[i]);
+  return r;
+}
+
 // TWO stages (Q, Q + 1) in registers: every thread owns the four elements that differ in bits Q - 1 and Q of
 // `mid` — one LDS round trip, one barrier and one index computation for two stages (round 1 ran every stage
 // through LDS; without the multiplications that skeleton alone took 0.29 of the 0.75 ms at 2^22,
@@ -216,15 +243,16 @@ __device__ __forceinline__ void fft_stage2(u32* lds, const PassArgs& a, int T, i
   const auto w2a = TW::load(a.tw + (size_t)t2a * 8);
   const auto w2b = TW::load(a.tw + (size_t)t2b * 8);
   const auto p = mul(w1, x01), q = mul(w1, x11);
-  const Fe<FrP, BIN + 32> a0 = add(x00, p), a1 = sub(x00, p), b0 = add(x10, q), b1 = sub(x10, q);
+  const Fe<FrP, BIN + 32> a0 = add(x00, p), a1 = sub(x00, p), b0 = add_nc(x10, q), b1 = sub_nc(x10, q);
   const auto u = mul(w2a, b0), v = mul(w2b, b1);
-  const Fe<FrP, BIN + 64> y00 = add(a0, u), y10 = sub(a0, u), y01 = add(a1, v), y11 = sub(a1, v);
   if constexpr (DST_G) {
+    const Fe<FrP, BIN + 64> y00 = add(a0, u), y10 = sub(a0, u), y01 = add(a1, v), y11 = sub(a1, v);
     gstore<FIRST, TILE>(a, T, logT, m00, ul, y00, last);
     gstore<FIRST, TILE>(a, T, logT, m01, ul, y01, last);
     gstore<FIRST, TILE>(a, T, logT, m10, ul, y10, last);
     gstore<FIRST, TILE>(a, T, logT, m11, ul, y11, last);
   } else {
+    const Fe<FrP, BIN + 64> y00 = add_nc(a0, u), y10 = sub_nc(a0, u), y01 = add_nc(a1, v), y11 = sub_nc(a1, v);
     lds_store<TILE>(lds, e00, y00);
     lds_store<TILE>(lds, e10, y10);
     lds_store<TILE>(lds, e01, y01);
@@ -295,7 +323,8 @@ __device__ __forceinline__ void fft_store_tile(u32* lds, const PassArgs& a, int 
     const u32 ul = FIRST ? (e >> (31 - __clz(TILE / T))) : (e & (u32)(T - 1));
     const u32 mid = FIRST ? (e & (u32)(TILE / T - 1)) : (e >> logT);
     const u32 i = tile_index<FIRST>(a, blockIdx.x, T, logT, mid, ul);
-    const auto v = lds_load<BEND, TILE>(lds, mid * T + ul);
+    auto v = lds_load<BEND, TILE>(lds, mid * T + ul);
+    fe_carry(v);   // (a pair leaves its outputs uncarried in LDS)
     u32 o[8];
     if (last) {
       pack(canonical(v), o);
