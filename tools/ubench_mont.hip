@@ -134,11 +134,195 @@ __device__ __forceinline__ Fe mul_E(const Fe& a, const Fe& b){
   r.l[8]=(u32)acc;
   return r;
 }
+// F / G / H: variant E with the 64-bit shift between columns replaced by v_alignbit_b32 + v_lshrrev_b32 (F, G) and
+// the m digit (low 29 bits of acc * PINV) computed with 24-bit multiplies instead of v_mul_lo_u32 (G, H): both move
+// work off the multiplier's pipe onto full-rate instructions.
+__device__ __forceinline__ void shr29(u64& acc){
+  u32 lo=(u32)acc, hi=(u32)(acc>>32), nlo, nhi;
+  asm("v_alignbit_b32 %0, %1, %2, 29" : "=v"(nlo) : "v"(hi), "v"(lo));
+  asm("v_lshrrev_b32 %0, 29, %1" : "=v"(nhi) : "v"(hi));
+  acc = ((u64)nhi<<32)|nlo;
+}
+__device__ __forceinline__ u32 mdig24(u32 lo){
+  constexpr u32 P24 = PINV & 0xffffffu, PH = PINV >> 24;
+  const u32 lohi = (lo >> 24) & 0x1fu;
+  const u32 t1 = __umul24(lo, P24);
+  const u32 t2 = __umul24(lo, PH) + __umul24(lohi, P24);
+  return (t1 + (t2 << 24)) & MASK;
+}
+__device__ __forceinline__ Fe mul_F(const Fe& a, const Fe& b){
+  u64 acc=0; u32 m[9]; Fe r;
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a.l[0]), "v"(b.l[0]) : "vcc");
+  m[0] = ((u32)acc * PINV) & MASK; acc = mad(m[0], PL[0], acc); shr29(acc);
+  asm("v_mad_u64_u32 %0, vcc, %1, %3, %0\n\tv_mad_u64_u32 %0, vcc, %2, %4, %0" : "+v"(acc) : "v"(a.l[0]), "v"(a.l[1]), "v"(b.l[1]), "v"(b.l[0]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(m[0]), "s"(PL[1]) : "vcc");
+  m[1] = ((u32)acc * PINV) & MASK; acc = mad(m[1], PL[0], acc); shr29(acc);
+  asm("v_mad_u64_u32 %0, vcc, %1, %4, %0\n\tv_mad_u64_u32 %0, vcc, %2, %5, %0\n\tv_mad_u64_u32 %0, vcc, %3, %6, %0" : "+v"(acc) : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(b.l[2]), "v"(b.l[1]), "v"(b.l[0]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %3, %0\n\tv_mad_u64_u32 %0, vcc, %2, %4, %0" : "+v"(acc) : "v"(m[0]), "v"(m[1]), "s"(PL[2]), "s"(PL[1]) : "vcc");
+  m[2] = ((u32)acc * PINV) & MASK; acc = mad(m[2], PL[0], acc); shr29(acc);
+  asm("v_mad_u64_u32 %0, vcc, %1, %5, %0\n\tv_mad_u64_u32 %0, vcc, %2, %6, %0\n\tv_mad_u64_u32 %0, vcc, %3, %7, %0\n\tv_mad_u64_u32 %0, vcc, %4, %8, %0" : "+v"(acc) : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(b.l[3]), "v"(b.l[2]), "v"(b.l[1]), "v"(b.l[0]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %4, %0\n\tv_mad_u64_u32 %0, vcc, %2, %5, %0\n\tv_mad_u64_u32 %0, vcc, %3, %6, %0" : "+v"(acc) : "v"(m[0]), "v"(m[1]), "v"(m[2]), "s"(PL[3]), "s"(PL[2]), "s"(PL[1]) : "vcc");
+  m[3] = ((u32)acc * PINV) & MASK; acc = mad(m[3], PL[0], acc); shr29(acc);
+  asm("v_mad_u64_u32 %0, vcc, %1, %6, %0\n\tv_mad_u64_u32 %0, vcc, %2, %7, %0\n\tv_mad_u64_u32 %0, vcc, %3, %8, %0\n\tv_mad_u64_u32 %0, vcc, %4, %9, %0\n\tv_mad_u64_u32 %0, vcc, %5, %10, %0" : "+v"(acc) : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(b.l[4]), "v"(b.l[3]), "v"(b.l[2]), "v"(b.l[1]), "v"(b.l[0]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %5, %0\n\tv_mad_u64_u32 %0, vcc, %2, %6, %0\n\tv_mad_u64_u32 %0, vcc, %3, %7, %0\n\tv_mad_u64_u32 %0, vcc, %4, %8, %0" : "+v"(acc) : "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "s"(PL[4]), "s"(PL[3]), "s"(PL[2]), "s"(PL[1]) : "vcc");
+  m[4] = ((u32)acc * PINV) & MASK; acc = mad(m[4], PL[0], acc); shr29(acc);
+  asm("v_mad_u64_u32 %0, vcc, %1, %7, %0\n\tv_mad_u64_u32 %0, vcc, %2, %8, %0\n\tv_mad_u64_u32 %0, vcc, %3, %9, %0\n\tv_mad_u64_u32 %0, vcc, %4, %10, %0\n\tv_mad_u64_u32 %0, vcc, %5, %11, %0\n\tv_mad_u64_u32 %0, vcc, %6, %12, %0" : "+v"(acc) : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(b.l[5]), "v"(b.l[4]), "v"(b.l[3]), "v"(b.l[2]), "v"(b.l[1]), "v"(b.l[0]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %6, %0\n\tv_mad_u64_u32 %0, vcc, %2, %7, %0\n\tv_mad_u64_u32 %0, vcc, %3, %8, %0\n\tv_mad_u64_u32 %0, vcc, %4, %9, %0\n\tv_mad_u64_u32 %0, vcc, %5, %10, %0" : "+v"(acc) : "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "s"(PL[5]), "s"(PL[4]), "s"(PL[3]), "s"(PL[2]), "s"(PL[1]) : "vcc");
+  m[5] = ((u32)acc * PINV) & MASK; acc = mad(m[5], PL[0], acc); shr29(acc);
+  asm("v_mad_u64_u32 %0, vcc, %1, %8, %0\n\tv_mad_u64_u32 %0, vcc, %2, %9, %0\n\tv_mad_u64_u32 %0, vcc, %3, %10, %0\n\tv_mad_u64_u32 %0, vcc, %4, %11, %0\n\tv_mad_u64_u32 %0, vcc, %5, %12, %0\n\tv_mad_u64_u32 %0, vcc, %6, %13, %0\n\tv_mad_u64_u32 %0, vcc, %7, %14, %0" : "+v"(acc) : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(b.l[6]), "v"(b.l[5]), "v"(b.l[4]), "v"(b.l[3]), "v"(b.l[2]), "v"(b.l[1]), "v"(b.l[0]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %7, %0\n\tv_mad_u64_u32 %0, vcc, %2, %8, %0\n\tv_mad_u64_u32 %0, vcc, %3, %9, %0\n\tv_mad_u64_u32 %0, vcc, %4, %10, %0\n\tv_mad_u64_u32 %0, vcc, %5, %11, %0\n\tv_mad_u64_u32 %0, vcc, %6, %12, %0" : "+v"(acc) : "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "s"(PL[6]), "s"(PL[5]), "s"(PL[4]), "s"(PL[3]), "s"(PL[2]), "s"(PL[1]) : "vcc");
+  m[6] = ((u32)acc * PINV) & MASK; acc = mad(m[6], PL[0], acc); shr29(acc);
+  asm("v_mad_u64_u32 %0, vcc, %1, %9, %0\n\tv_mad_u64_u32 %0, vcc, %2, %10, %0\n\tv_mad_u64_u32 %0, vcc, %3, %11, %0\n\tv_mad_u64_u32 %0, vcc, %4, %12, %0\n\tv_mad_u64_u32 %0, vcc, %5, %13, %0\n\tv_mad_u64_u32 %0, vcc, %6, %14, %0\n\tv_mad_u64_u32 %0, vcc, %7, %15, %0\n\tv_mad_u64_u32 %0, vcc, %8, %16, %0" : "+v"(acc) : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]), "v"(b.l[7]), "v"(b.l[6]), "v"(b.l[5]), "v"(b.l[4]), "v"(b.l[3]), "v"(b.l[2]), "v"(b.l[1]), "v"(b.l[0]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %8, %0\n\tv_mad_u64_u32 %0, vcc, %2, %9, %0\n\tv_mad_u64_u32 %0, vcc, %3, %10, %0\n\tv_mad_u64_u32 %0, vcc, %4, %11, %0\n\tv_mad_u64_u32 %0, vcc, %5, %12, %0\n\tv_mad_u64_u32 %0, vcc, %6, %13, %0\n\tv_mad_u64_u32 %0, vcc, %7, %14, %0" : "+v"(acc) : "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "s"(PL[7]), "s"(PL[6]), "s"(PL[5]), "s"(PL[4]), "s"(PL[3]), "s"(PL[2]), "s"(PL[1]) : "vcc");
+  m[7] = ((u32)acc * PINV) & MASK; acc = mad(m[7], PL[0], acc); shr29(acc);
+  asm("v_mad_u64_u32 %0, vcc, %1, %10, %0\n\tv_mad_u64_u32 %0, vcc, %2, %11, %0\n\tv_mad_u64_u32 %0, vcc, %3, %12, %0\n\tv_mad_u64_u32 %0, vcc, %4, %13, %0\n\tv_mad_u64_u32 %0, vcc, %5, %14, %0\n\tv_mad_u64_u32 %0, vcc, %6, %15, %0\n\tv_mad_u64_u32 %0, vcc, %7, %16, %0\n\tv_mad_u64_u32 %0, vcc, %8, %17, %0\n\tv_mad_u64_u32 %0, vcc, %9, %18, %0" : "+v"(acc) : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]), "v"(a.l[8]), "v"(b.l[8]), "v"(b.l[7]), "v"(b.l[6]), "v"(b.l[5]), "v"(b.l[4]), "v"(b.l[3]), "v"(b.l[2]), "v"(b.l[1]), "v"(b.l[0]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %9, %0\n\tv_mad_u64_u32 %0, vcc, %2, %10, %0\n\tv_mad_u64_u32 %0, vcc, %3, %11, %0\n\tv_mad_u64_u32 %0, vcc, %4, %12, %0\n\tv_mad_u64_u32 %0, vcc, %5, %13, %0\n\tv_mad_u64_u32 %0, vcc, %6, %14, %0\n\tv_mad_u64_u32 %0, vcc, %7, %15, %0\n\tv_mad_u64_u32 %0, vcc, %8, %16, %0" : "+v"(acc) : "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "s"(PL[8]), "s"(PL[7]), "s"(PL[6]), "s"(PL[5]), "s"(PL[4]), "s"(PL[3]), "s"(PL[2]), "s"(PL[1]) : "vcc");
+  m[8] = ((u32)acc * PINV) & MASK; acc = mad(m[8], PL[0], acc); shr29(acc);
+  asm("v_mad_u64_u32 %0, vcc, %1, %9, %0\n\tv_mad_u64_u32 %0, vcc, %2, %10, %0\n\tv_mad_u64_u32 %0, vcc, %3, %11, %0\n\tv_mad_u64_u32 %0, vcc, %4, %12, %0\n\tv_mad_u64_u32 %0, vcc, %5, %13, %0\n\tv_mad_u64_u32 %0, vcc, %6, %14, %0\n\tv_mad_u64_u32 %0, vcc, %7, %15, %0\n\tv_mad_u64_u32 %0, vcc, %8, %16, %0" : "+v"(acc) : "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]), "v"(a.l[8]), "v"(b.l[8]), "v"(b.l[7]), "v"(b.l[6]), "v"(b.l[5]), "v"(b.l[4]), "v"(b.l[3]), "v"(b.l[2]), "v"(b.l[1]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %9, %0\n\tv_mad_u64_u32 %0, vcc, %2, %10, %0\n\tv_mad_u64_u32 %0, vcc, %3, %11, %0\n\tv_mad_u64_u32 %0, vcc, %4, %12, %0\n\tv_mad_u64_u32 %0, vcc, %5, %13, %0\n\tv_mad_u64_u32 %0, vcc, %6, %14, %0\n\tv_mad_u64_u32 %0, vcc, %7, %15, %0\n\tv_mad_u64_u32 %0, vcc, %8, %16, %0" : "+v"(acc) : "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "s"(PL[8]), "s"(PL[7]), "s"(PL[6]), "s"(PL[5]), "s"(PL[4]), "s"(PL[3]), "s"(PL[2]), "s"(PL[1]) : "vcc");
+  r.l[0] = (u32)acc & MASK; shr29(acc);
+  asm("v_mad_u64_u32 %0, vcc, %1, %8, %0\n\tv_mad_u64_u32 %0, vcc, %2, %9, %0\n\tv_mad_u64_u32 %0, vcc, %3, %10, %0\n\tv_mad_u64_u32 %0, vcc, %4, %11, %0\n\tv_mad_u64_u32 %0, vcc, %5, %12, %0\n\tv_mad_u64_u32 %0, vcc, %6, %13, %0\n\tv_mad_u64_u32 %0, vcc, %7, %14, %0" : "+v"(acc) : "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]), "v"(a.l[8]), "v"(b.l[8]), "v"(b.l[7]), "v"(b.l[6]), "v"(b.l[5]), "v"(b.l[4]), "v"(b.l[3]), "v"(b.l[2]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %8, %0\n\tv_mad_u64_u32 %0, vcc, %2, %9, %0\n\tv_mad_u64_u32 %0, vcc, %3, %10, %0\n\tv_mad_u64_u32 %0, vcc, %4, %11, %0\n\tv_mad_u64_u32 %0, vcc, %5, %12, %0\n\tv_mad_u64_u32 %0, vcc, %6, %13, %0\n\tv_mad_u64_u32 %0, vcc, %7, %14, %0" : "+v"(acc) : "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "s"(PL[8]), "s"(PL[7]), "s"(PL[6]), "s"(PL[5]), "s"(PL[4]), "s"(PL[3]), "s"(PL[2]) : "vcc");
+  r.l[1] = (u32)acc & MASK; shr29(acc);
+  asm("v_mad_u64_u32 %0, vcc, %1, %7, %0\n\tv_mad_u64_u32 %0, vcc, %2, %8, %0\n\tv_mad_u64_u32 %0, vcc, %3, %9, %0\n\tv_mad_u64_u32 %0, vcc, %4, %10, %0\n\tv_mad_u64_u32 %0, vcc, %5, %11, %0\n\tv_mad_u64_u32 %0, vcc, %6, %12, %0" : "+v"(acc) : "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]), "v"(a.l[8]), "v"(b.l[8]), "v"(b.l[7]), "v"(b.l[6]), "v"(b.l[5]), "v"(b.l[4]), "v"(b.l[3]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %7, %0\n\tv_mad_u64_u32 %0, vcc, %2, %8, %0\n\tv_mad_u64_u32 %0, vcc, %3, %9, %0\n\tv_mad_u64_u32 %0, vcc, %4, %10, %0\n\tv_mad_u64_u32 %0, vcc, %5, %11, %0\n\tv_mad_u64_u32 %0, vcc, %6, %12, %0" : "+v"(acc) : "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "s"(PL[8]), "s"(PL[7]), "s"(PL[6]), "s"(PL[5]), "s"(PL[4]), "s"(PL[3]) : "vcc");
+  r.l[2] = (u32)acc & MASK; shr29(acc);
+  asm("v_mad_u64_u32 %0, vcc, %1, %6, %0\n\tv_mad_u64_u32 %0, vcc, %2, %7, %0\n\tv_mad_u64_u32 %0, vcc, %3, %8, %0\n\tv_mad_u64_u32 %0, vcc, %4, %9, %0\n\tv_mad_u64_u32 %0, vcc, %5, %10, %0" : "+v"(acc) : "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]), "v"(a.l[8]), "v"(b.l[8]), "v"(b.l[7]), "v"(b.l[6]), "v"(b.l[5]), "v"(b.l[4]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %6, %0\n\tv_mad_u64_u32 %0, vcc, %2, %7, %0\n\tv_mad_u64_u32 %0, vcc, %3, %8, %0\n\tv_mad_u64_u32 %0, vcc, %4, %9, %0\n\tv_mad_u64_u32 %0, vcc, %5, %10, %0" : "+v"(acc) : "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "s"(PL[8]), "s"(PL[7]), "s"(PL[6]), "s"(PL[5]), "s"(PL[4]) : "vcc");
+  r.l[3] = (u32)acc & MASK; shr29(acc);
+  asm("v_mad_u64_u32 %0, vcc, %1, %5, %0\n\tv_mad_u64_u32 %0, vcc, %2, %6, %0\n\tv_mad_u64_u32 %0, vcc, %3, %7, %0\n\tv_mad_u64_u32 %0, vcc, %4, %8, %0" : "+v"(acc) : "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]), "v"(a.l[8]), "v"(b.l[8]), "v"(b.l[7]), "v"(b.l[6]), "v"(b.l[5]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %5, %0\n\tv_mad_u64_u32 %0, vcc, %2, %6, %0\n\tv_mad_u64_u32 %0, vcc, %3, %7, %0\n\tv_mad_u64_u32 %0, vcc, %4, %8, %0" : "+v"(acc) : "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "s"(PL[8]), "s"(PL[7]), "s"(PL[6]), "s"(PL[5]) : "vcc");
+  r.l[4] = (u32)acc & MASK; shr29(acc);
+  asm("v_mad_u64_u32 %0, vcc, %1, %4, %0\n\tv_mad_u64_u32 %0, vcc, %2, %5, %0\n\tv_mad_u64_u32 %0, vcc, %3, %6, %0" : "+v"(acc) : "v"(a.l[6]), "v"(a.l[7]), "v"(a.l[8]), "v"(b.l[8]), "v"(b.l[7]), "v"(b.l[6]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %4, %0\n\tv_mad_u64_u32 %0, vcc, %2, %5, %0\n\tv_mad_u64_u32 %0, vcc, %3, %6, %0" : "+v"(acc) : "v"(m[6]), "v"(m[7]), "v"(m[8]), "s"(PL[8]), "s"(PL[7]), "s"(PL[6]) : "vcc");
+  r.l[5] = (u32)acc & MASK; shr29(acc);
+  asm("v_mad_u64_u32 %0, vcc, %1, %3, %0\n\tv_mad_u64_u32 %0, vcc, %2, %4, %0" : "+v"(acc) : "v"(a.l[7]), "v"(a.l[8]), "v"(b.l[8]), "v"(b.l[7]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %3, %0\n\tv_mad_u64_u32 %0, vcc, %2, %4, %0" : "+v"(acc) : "v"(m[7]), "v"(m[8]), "s"(PL[8]), "s"(PL[7]) : "vcc");
+  r.l[6] = (u32)acc & MASK; shr29(acc);
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a.l[8]), "v"(b.l[8]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(m[8]), "s"(PL[8]) : "vcc");
+  r.l[7] = (u32)acc & MASK; shr29(acc);
+  r.l[8]=(u32)acc;
+  return r;
+}
+__device__ __forceinline__ Fe mul_G(const Fe& a, const Fe& b){
+  u64 acc=0; u32 m[9]; Fe r;
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a.l[0]), "v"(b.l[0]) : "vcc");
+  m[0] = mdig24((u32)acc); acc = mad(m[0], PL[0], acc); shr29(acc);
+  asm("v_mad_u64_u32 %0, vcc, %1, %3, %0\n\tv_mad_u64_u32 %0, vcc, %2, %4, %0" : "+v"(acc) : "v"(a.l[0]), "v"(a.l[1]), "v"(b.l[1]), "v"(b.l[0]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(m[0]), "s"(PL[1]) : "vcc");
+  m[1] = mdig24((u32)acc); acc = mad(m[1], PL[0], acc); shr29(acc);
+  asm("v_mad_u64_u32 %0, vcc, %1, %4, %0\n\tv_mad_u64_u32 %0, vcc, %2, %5, %0\n\tv_mad_u64_u32 %0, vcc, %3, %6, %0" : "+v"(acc) : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(b.l[2]), "v"(b.l[1]), "v"(b.l[0]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %3, %0\n\tv_mad_u64_u32 %0, vcc, %2, %4, %0" : "+v"(acc) : "v"(m[0]), "v"(m[1]), "s"(PL[2]), "s"(PL[1]) : "vcc");
+  m[2] = mdig24((u32)acc); acc = mad(m[2], PL[0], acc); shr29(acc);
+  asm("v_mad_u64_u32 %0, vcc, %1, %5, %0\n\tv_mad_u64_u32 %0, vcc, %2, %6, %0\n\tv_mad_u64_u32 %0, vcc, %3, %7, %0\n\tv_mad_u64_u32 %0, vcc, %4, %8, %0" : "+v"(acc) : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(b.l[3]), "v"(b.l[2]), "v"(b.l[1]), "v"(b.l[0]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %4, %0\n\tv_mad_u64_u32 %0, vcc, %2, %5, %0\n\tv_mad_u64_u32 %0, vcc, %3, %6, %0" : "+v"(acc) : "v"(m[0]), "v"(m[1]), "v"(m[2]), "s"(PL[3]), "s"(PL[2]), "s"(PL[1]) : "vcc");
+  m[3] = mdig24((u32)acc); acc = mad(m[3], PL[0], acc); shr29(acc);
+  asm("v_mad_u64_u32 %0, vcc, %1, %6, %0\n\tv_mad_u64_u32 %0, vcc, %2, %7, %0\n\tv_mad_u64_u32 %0, vcc, %3, %8, %0\n\tv_mad_u64_u32 %0, vcc, %4, %9, %0\n\tv_mad_u64_u32 %0, vcc, %5, %10, %0" : "+v"(acc) : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(b.l[4]), "v"(b.l[3]), "v"(b.l[2]), "v"(b.l[1]), "v"(b.l[0]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %5, %0\n\tv_mad_u64_u32 %0, vcc, %2, %6, %0\n\tv_mad_u64_u32 %0, vcc, %3, %7, %0\n\tv_mad_u64_u32 %0, vcc, %4, %8, %0" : "+v"(acc) : "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "s"(PL[4]), "s"(PL[3]), "s"(PL[2]), "s"(PL[1]) : "vcc");
+  m[4] = mdig24((u32)acc); acc = mad(m[4], PL[0], acc); shr29(acc);
+  asm("v_mad_u64_u32 %0, vcc, %1, %7, %0\n\tv_mad_u64_u32 %0, vcc, %2, %8, %0\n\tv_mad_u64_u32 %0, vcc, %3, %9, %0\n\tv_mad_u64_u32 %0, vcc, %4, %10, %0\n\tv_mad_u64_u32 %0, vcc, %5, %11, %0\n\tv_mad_u64_u32 %0, vcc, %6, %12, %0" : "+v"(acc) : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(b.l[5]), "v"(b.l[4]), "v"(b.l[3]), "v"(b.l[2]), "v"(b.l[1]), "v"(b.l[0]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %6, %0\n\tv_mad_u64_u32 %0, vcc, %2, %7, %0\n\tv_mad_u64_u32 %0, vcc, %3, %8, %0\n\tv_mad_u64_u32 %0, vcc, %4, %9, %0\n\tv_mad_u64_u32 %0, vcc, %5, %10, %0" : "+v"(acc) : "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "s"(PL[5]), "s"(PL[4]), "s"(PL[3]), "s"(PL[2]), "s"(PL[1]) : "vcc");
+  m[5] = mdig24((u32)acc); acc = mad(m[5], PL[0], acc); shr29(acc);
+  asm("v_mad_u64_u32 %0, vcc, %1, %8, %0\n\tv_mad_u64_u32 %0, vcc, %2, %9, %0\n\tv_mad_u64_u32 %0, vcc, %3, %10, %0\n\tv_mad_u64_u32 %0, vcc, %4, %11, %0\n\tv_mad_u64_u32 %0, vcc, %5, %12, %0\n\tv_mad_u64_u32 %0, vcc, %6, %13, %0\n\tv_mad_u64_u32 %0, vcc, %7, %14, %0" : "+v"(acc) : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(b.l[6]), "v"(b.l[5]), "v"(b.l[4]), "v"(b.l[3]), "v"(b.l[2]), "v"(b.l[1]), "v"(b.l[0]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %7, %0\n\tv_mad_u64_u32 %0, vcc, %2, %8, %0\n\tv_mad_u64_u32 %0, vcc, %3, %9, %0\n\tv_mad_u64_u32 %0, vcc, %4, %10, %0\n\tv_mad_u64_u32 %0, vcc, %5, %11, %0\n\tv_mad_u64_u32 %0, vcc, %6, %12, %0" : "+v"(acc) : "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "s"(PL[6]), "s"(PL[5]), "s"(PL[4]), "s"(PL[3]), "s"(PL[2]), "s"(PL[1]) : "vcc");
+  m[6] = mdig24((u32)acc); acc = mad(m[6], PL[0], acc); shr29(acc);
+  asm("v_mad_u64_u32 %0, vcc, %1, %9, %0\n\tv_mad_u64_u32 %0, vcc, %2, %10, %0\n\tv_mad_u64_u32 %0, vcc, %3, %11, %0\n\tv_mad_u64_u32 %0, vcc, %4, %12, %0\n\tv_mad_u64_u32 %0, vcc, %5, %13, %0\n\tv_mad_u64_u32 %0, vcc, %6, %14, %0\n\tv_mad_u64_u32 %0, vcc, %7, %15, %0\n\tv_mad_u64_u32 %0, vcc, %8, %16, %0" : "+v"(acc) : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]), "v"(b.l[7]), "v"(b.l[6]), "v"(b.l[5]), "v"(b.l[4]), "v"(b.l[3]), "v"(b.l[2]), "v"(b.l[1]), "v"(b.l[0]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %8, %0\n\tv_mad_u64_u32 %0, vcc, %2, %9, %0\n\tv_mad_u64_u32 %0, vcc, %3, %10, %0\n\tv_mad_u64_u32 %0, vcc, %4, %11, %0\n\tv_mad_u64_u32 %0, vcc, %5, %12, %0\n\tv_mad_u64_u32 %0, vcc, %6, %13, %0\n\tv_mad_u64_u32 %0, vcc, %7, %14, %0" : "+v"(acc) : "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "s"(PL[7]), "s"(PL[6]), "s"(PL[5]), "s"(PL[4]), "s"(PL[3]), "s"(PL[2]), "s"(PL[1]) : "vcc");
+  m[7] = mdig24((u32)acc); acc = mad(m[7], PL[0], acc); shr29(acc);
+  asm("v_mad_u64_u32 %0, vcc, %1, %10, %0\n\tv_mad_u64_u32 %0, vcc, %2, %11, %0\n\tv_mad_u64_u32 %0, vcc, %3, %12, %0\n\tv_mad_u64_u32 %0, vcc, %4, %13, %0\n\tv_mad_u64_u32 %0, vcc, %5, %14, %0\n\tv_mad_u64_u32 %0, vcc, %6, %15, %0\n\tv_mad_u64_u32 %0, vcc, %7, %16, %0\n\tv_mad_u64_u32 %0, vcc, %8, %17, %0\n\tv_mad_u64_u32 %0, vcc, %9, %18, %0" : "+v"(acc) : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]), "v"(a.l[8]), "v"(b.l[8]), "v"(b.l[7]), "v"(b.l[6]), "v"(b.l[5]), "v"(b.l[4]), "v"(b.l[3]), "v"(b.l[2]), "v"(b.l[1]), "v"(b.l[0]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %9, %0\n\tv_mad_u64_u32 %0, vcc, %2, %10, %0\n\tv_mad_u64_u32 %0, vcc, %3, %11, %0\n\tv_mad_u64_u32 %0, vcc, %4, %12, %0\n\tv_mad_u64_u32 %0, vcc, %5, %13, %0\n\tv_mad_u64_u32 %0, vcc, %6, %14, %0\n\tv_mad_u64_u32 %0, vcc, %7, %15, %0\n\tv_mad_u64_u32 %0, vcc, %8, %16, %0" : "+v"(acc) : "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "s"(PL[8]), "s"(PL[7]), "s"(PL[6]), "s"(PL[5]), "s"(PL[4]), "s"(PL[3]), "s"(PL[2]), "s"(PL[1]) : "vcc");
+  m[8] = mdig24((u32)acc); acc = mad(m[8], PL[0], acc); shr29(acc);
+  asm("v_mad_u64_u32 %0, vcc, %1, %9, %0\n\tv_mad_u64_u32 %0, vcc, %2, %10, %0\n\tv_mad_u64_u32 %0, vcc, %3, %11, %0\n\tv_mad_u64_u32 %0, vcc, %4, %12, %0\n\tv_mad_u64_u32 %0, vcc, %5, %13, %0\n\tv_mad_u64_u32 %0, vcc, %6, %14, %0\n\tv_mad_u64_u32 %0, vcc, %7, %15, %0\n\tv_mad_u64_u32 %0, vcc, %8, %16, %0" : "+v"(acc) : "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]), "v"(a.l[8]), "v"(b.l[8]), "v"(b.l[7]), "v"(b.l[6]), "v"(b.l[5]), "v"(b.l[4]), "v"(b.l[3]), "v"(b.l[2]), "v"(b.l[1]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %9, %0\n\tv_mad_u64_u32 %0, vcc, %2, %10, %0\n\tv_mad_u64_u32 %0, vcc, %3, %11, %0\n\tv_mad_u64_u32 %0, vcc, %4, %12, %0\n\tv_mad_u64_u32 %0, vcc, %5, %13, %0\n\tv_mad_u64_u32 %0, vcc, %6, %14, %0\n\tv_mad_u64_u32 %0, vcc, %7, %15, %0\n\tv_mad_u64_u32 %0, vcc, %8, %16, %0" : "+v"(acc) : "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "s"(PL[8]), "s"(PL[7]), "s"(PL[6]), "s"(PL[5]), "s"(PL[4]), "s"(PL[3]), "s"(PL[2]), "s"(PL[1]) : "vcc");
+  r.l[0] = (u32)acc & MASK; shr29(acc);
+  asm("v_mad_u64_u32 %0, vcc, %1, %8, %0\n\tv_mad_u64_u32 %0, vcc, %2, %9, %0\n\tv_mad_u64_u32 %0, vcc, %3, %10, %0\n\tv_mad_u64_u32 %0, vcc, %4, %11, %0\n\tv_mad_u64_u32 %0, vcc, %5, %12, %0\n\tv_mad_u64_u32 %0, vcc, %6, %13, %0\n\tv_mad_u64_u32 %0, vcc, %7, %14, %0" : "+v"(acc) : "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]), "v"(a.l[8]), "v"(b.l[8]), "v"(b.l[7]), "v"(b.l[6]), "v"(b.l[5]), "v"(b.l[4]), "v"(b.l[3]), "v"(b.l[2]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %8, %0\n\tv_mad_u64_u32 %0, vcc, %2, %9, %0\n\tv_mad_u64_u32 %0, vcc, %3, %10, %0\n\tv_mad_u64_u32 %0, vcc, %4, %11, %0\n\tv_mad_u64_u32 %0, vcc, %5, %12, %0\n\tv_mad_u64_u32 %0, vcc, %6, %13, %0\n\tv_mad_u64_u32 %0, vcc, %7, %14, %0" : "+v"(acc) : "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "s"(PL[8]), "s"(PL[7]), "s"(PL[6]), "s"(PL[5]), "s"(PL[4]), "s"(PL[3]), "s"(PL[2]) : "vcc");
+  r.l[1] = (u32)acc & MASK; shr29(acc);
+  asm("v_mad_u64_u32 %0, vcc, %1, %7, %0\n\tv_mad_u64_u32 %0, vcc, %2, %8, %0\n\tv_mad_u64_u32 %0, vcc, %3, %9, %0\n\tv_mad_u64_u32 %0, vcc, %4, %10, %0\n\tv_mad_u64_u32 %0, vcc, %5, %11, %0\n\tv_mad_u64_u32 %0, vcc, %6, %12, %0" : "+v"(acc) : "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]), "v"(a.l[8]), "v"(b.l[8]), "v"(b.l[7]), "v"(b.l[6]), "v"(b.l[5]), "v"(b.l[4]), "v"(b.l[3]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %7, %0\n\tv_mad_u64_u32 %0, vcc, %2, %8, %0\n\tv_mad_u64_u32 %0, vcc, %3, %9, %0\n\tv_mad_u64_u32 %0, vcc, %4, %10, %0\n\tv_mad_u64_u32 %0, vcc, %5, %11, %0\n\tv_mad_u64_u32 %0, vcc, %6, %12, %0" : "+v"(acc) : "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "s"(PL[8]), "s"(PL[7]), "s"(PL[6]), "s"(PL[5]), "s"(PL[4]), "s"(PL[3]) : "vcc");
+  r.l[2] = (u32)acc & MASK; shr29(acc);
+  asm("v_mad_u64_u32 %0, vcc, %1, %6, %0\n\tv_mad_u64_u32 %0, vcc, %2, %7, %0\n\tv_mad_u64_u32 %0, vcc, %3, %8, %0\n\tv_mad_u64_u32 %0, vcc, %4, %9, %0\n\tv_mad_u64_u32 %0, vcc, %5, %10, %0" : "+v"(acc) : "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]), "v"(a.l[8]), "v"(b.l[8]), "v"(b.l[7]), "v"(b.l[6]), "v"(b.l[5]), "v"(b.l[4]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %6, %0\n\tv_mad_u64_u32 %0, vcc, %2, %7, %0\n\tv_mad_u64_u32 %0, vcc, %3, %8, %0\n\tv_mad_u64_u32 %0, vcc, %4, %9, %0\n\tv_mad_u64_u32 %0, vcc, %5, %10, %0" : "+v"(acc) : "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "s"(PL[8]), "s"(PL[7]), "s"(PL[6]), "s"(PL[5]), "s"(PL[4]) : "vcc");
+  r.l[3] = (u32)acc & MASK; shr29(acc);
+  asm("v_mad_u64_u32 %0, vcc, %1, %5, %0\n\tv_mad_u64_u32 %0, vcc, %2, %6, %0\n\tv_mad_u64_u32 %0, vcc, %3, %7, %0\n\tv_mad_u64_u32 %0, vcc, %4, %8, %0" : "+v"(acc) : "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]), "v"(a.l[8]), "v"(b.l[8]), "v"(b.l[7]), "v"(b.l[6]), "v"(b.l[5]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %5, %0\n\tv_mad_u64_u32 %0, vcc, %2, %6, %0\n\tv_mad_u64_u32 %0, vcc, %3, %7, %0\n\tv_mad_u64_u32 %0, vcc, %4, %8, %0" : "+v"(acc) : "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "s"(PL[8]), "s"(PL[7]), "s"(PL[6]), "s"(PL[5]) : "vcc");
+  r.l[4] = (u32)acc & MASK; shr29(acc);
+  asm("v_mad_u64_u32 %0, vcc, %1, %4, %0\n\tv_mad_u64_u32 %0, vcc, %2, %5, %0\n\tv_mad_u64_u32 %0, vcc, %3, %6, %0" : "+v"(acc) : "v"(a.l[6]), "v"(a.l[7]), "v"(a.l[8]), "v"(b.l[8]), "v"(b.l[7]), "v"(b.l[6]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %4, %0\n\tv_mad_u64_u32 %0, vcc, %2, %5, %0\n\tv_mad_u64_u32 %0, vcc, %3, %6, %0" : "+v"(acc) : "v"(m[6]), "v"(m[7]), "v"(m[8]), "s"(PL[8]), "s"(PL[7]), "s"(PL[6]) : "vcc");
+  r.l[5] = (u32)acc & MASK; shr29(acc);
+  asm("v_mad_u64_u32 %0, vcc, %1, %3, %0\n\tv_mad_u64_u32 %0, vcc, %2, %4, %0" : "+v"(acc) : "v"(a.l[7]), "v"(a.l[8]), "v"(b.l[8]), "v"(b.l[7]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %3, %0\n\tv_mad_u64_u32 %0, vcc, %2, %4, %0" : "+v"(acc) : "v"(m[7]), "v"(m[8]), "s"(PL[8]), "s"(PL[7]) : "vcc");
+  r.l[6] = (u32)acc & MASK; shr29(acc);
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a.l[8]), "v"(b.l[8]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(m[8]), "s"(PL[8]) : "vcc");
+  r.l[7] = (u32)acc & MASK; shr29(acc);
+  r.l[8]=(u32)acc;
+  return r;
+}
+__device__ __forceinline__ Fe mul_H(const Fe& a, const Fe& b){
+  u64 acc=0; u32 m[9]; Fe r;
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a.l[0]), "v"(b.l[0]) : "vcc");
+  m[0] = mdig24((u32)acc); acc = mad(m[0], PL[0], acc); acc >>= 29;
+  asm("v_mad_u64_u32 %0, vcc, %1, %3, %0\n\tv_mad_u64_u32 %0, vcc, %2, %4, %0" : "+v"(acc) : "v"(a.l[0]), "v"(a.l[1]), "v"(b.l[1]), "v"(b.l[0]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(m[0]), "s"(PL[1]) : "vcc");
+  m[1] = mdig24((u32)acc); acc = mad(m[1], PL[0], acc); acc >>= 29;
+  asm("v_mad_u64_u32 %0, vcc, %1, %4, %0\n\tv_mad_u64_u32 %0, vcc, %2, %5, %0\n\tv_mad_u64_u32 %0, vcc, %3, %6, %0" : "+v"(acc) : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(b.l[2]), "v"(b.l[1]), "v"(b.l[0]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %3, %0\n\tv_mad_u64_u32 %0, vcc, %2, %4, %0" : "+v"(acc) : "v"(m[0]), "v"(m[1]), "s"(PL[2]), "s"(PL[1]) : "vcc");
+  m[2] = mdig24((u32)acc); acc = mad(m[2], PL[0], acc); acc >>= 29;
+  asm("v_mad_u64_u32 %0, vcc, %1, %5, %0\n\tv_mad_u64_u32 %0, vcc, %2, %6, %0\n\tv_mad_u64_u32 %0, vcc, %3, %7, %0\n\tv_mad_u64_u32 %0, vcc, %4, %8, %0" : "+v"(acc) : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(b.l[3]), "v"(b.l[2]), "v"(b.l[1]), "v"(b.l[0]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %4, %0\n\tv_mad_u64_u32 %0, vcc, %2, %5, %0\n\tv_mad_u64_u32 %0, vcc, %3, %6, %0" : "+v"(acc) : "v"(m[0]), "v"(m[1]), "v"(m[2]), "s"(PL[3]), "s"(PL[2]), "s"(PL[1]) : "vcc");
+  m[3] = mdig24((u32)acc); acc = mad(m[3], PL[0], acc); acc >>= 29;
+  asm("v_mad_u64_u32 %0, vcc, %1, %6, %0\n\tv_mad_u64_u32 %0, vcc, %2, %7, %0\n\tv_mad_u64_u32 %0, vcc, %3, %8, %0\n\tv_mad_u64_u32 %0, vcc, %4, %9, %0\n\tv_mad_u64_u32 %0, vcc, %5, %10, %0" : "+v"(acc) : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(b.l[4]), "v"(b.l[3]), "v"(b.l[2]), "v"(b.l[1]), "v"(b.l[0]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %5, %0\n\tv_mad_u64_u32 %0, vcc, %2, %6, %0\n\tv_mad_u64_u32 %0, vcc, %3, %7, %0\n\tv_mad_u64_u32 %0, vcc, %4, %8, %0" : "+v"(acc) : "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "s"(PL[4]), "s"(PL[3]), "s"(PL[2]), "s"(PL[1]) : "vcc");
+  m[4] = mdig24((u32)acc); acc = mad(m[4], PL[0], acc); acc >>= 29;
+  asm("v_mad_u64_u32 %0, vcc, %1, %7, %0\n\tv_mad_u64_u32 %0, vcc, %2, %8, %0\n\tv_mad_u64_u32 %0, vcc, %3, %9, %0\n\tv_mad_u64_u32 %0, vcc, %4, %10, %0\n\tv_mad_u64_u32 %0, vcc, %5, %11, %0\n\tv_mad_u64_u32 %0, vcc, %6, %12, %0" : "+v"(acc) : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(b.l[5]), "v"(b.l[4]), "v"(b.l[3]), "v"(b.l[2]), "v"(b.l[1]), "v"(b.l[0]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %6, %0\n\tv_mad_u64_u32 %0, vcc, %2, %7, %0\n\tv_mad_u64_u32 %0, vcc, %3, %8, %0\n\tv_mad_u64_u32 %0, vcc, %4, %9, %0\n\tv_mad_u64_u32 %0, vcc, %5, %10, %0" : "+v"(acc) : "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "s"(PL[5]), "s"(PL[4]), "s"(PL[3]), "s"(PL[2]), "s"(PL[1]) : "vcc");
+  m[5] = mdig24((u32)acc); acc = mad(m[5], PL[0], acc); acc >>= 29;
+  asm("v_mad_u64_u32 %0, vcc, %1, %8, %0\n\tv_mad_u64_u32 %0, vcc, %2, %9, %0\n\tv_mad_u64_u32 %0, vcc, %3, %10, %0\n\tv_mad_u64_u32 %0, vcc, %4, %11, %0\n\tv_mad_u64_u32 %0, vcc, %5, %12, %0\n\tv_mad_u64_u32 %0, vcc, %6, %13, %0\n\tv_mad_u64_u32 %0, vcc, %7, %14, %0" : "+v"(acc) : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(b.l[6]), "v"(b.l[5]), "v"(b.l[4]), "v"(b.l[3]), "v"(b.l[2]), "v"(b.l[1]), "v"(b.l[0]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %7, %0\n\tv_mad_u64_u32 %0, vcc, %2, %8, %0\n\tv_mad_u64_u32 %0, vcc, %3, %9, %0\n\tv_mad_u64_u32 %0, vcc, %4, %10, %0\n\tv_mad_u64_u32 %0, vcc, %5, %11, %0\n\tv_mad_u64_u32 %0, vcc, %6, %12, %0" : "+v"(acc) : "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "s"(PL[6]), "s"(PL[5]), "s"(PL[4]), "s"(PL[3]), "s"(PL[2]), "s"(PL[1]) : "vcc");
+  m[6] = mdig24((u32)acc); acc = mad(m[6], PL[0], acc); acc >>= 29;
+  asm("v_mad_u64_u32 %0, vcc, %1, %9, %0\n\tv_mad_u64_u32 %0, vcc, %2, %10, %0\n\tv_mad_u64_u32 %0, vcc, %3, %11, %0\n\tv_mad_u64_u32 %0, vcc, %4, %12, %0\n\tv_mad_u64_u32 %0, vcc, %5, %13, %0\n\tv_mad_u64_u32 %0, vcc, %6, %14, %0\n\tv_mad_u64_u32 %0, vcc, %7, %15, %0\n\tv_mad_u64_u32 %0, vcc, %8, %16, %0" : "+v"(acc) : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]), "v"(b.l[7]), "v"(b.l[6]), "v"(b.l[5]), "v"(b.l[4]), "v"(b.l[3]), "v"(b.l[2]), "v"(b.l[1]), "v"(b.l[0]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %8, %0\n\tv_mad_u64_u32 %0, vcc, %2, %9, %0\n\tv_mad_u64_u32 %0, vcc, %3, %10, %0\n\tv_mad_u64_u32 %0, vcc, %4, %11, %0\n\tv_mad_u64_u32 %0, vcc, %5, %12, %0\n\tv_mad_u64_u32 %0, vcc, %6, %13, %0\n\tv_mad_u64_u32 %0, vcc, %7, %14, %0" : "+v"(acc) : "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "s"(PL[7]), "s"(PL[6]), "s"(PL[5]), "s"(PL[4]), "s"(PL[3]), "s"(PL[2]), "s"(PL[1]) : "vcc");
+  m[7] = mdig24((u32)acc); acc = mad(m[7], PL[0], acc); acc >>= 29;
+  asm("v_mad_u64_u32 %0, vcc, %1, %10, %0\n\tv_mad_u64_u32 %0, vcc, %2, %11, %0\n\tv_mad_u64_u32 %0, vcc, %3, %12, %0\n\tv_mad_u64_u32 %0, vcc, %4, %13, %0\n\tv_mad_u64_u32 %0, vcc, %5, %14, %0\n\tv_mad_u64_u32 %0, vcc, %6, %15, %0\n\tv_mad_u64_u32 %0, vcc, %7, %16, %0\n\tv_mad_u64_u32 %0, vcc, %8, %17, %0\n\tv_mad_u64_u32 %0, vcc, %9, %18, %0" : "+v"(acc) : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]), "v"(a.l[8]), "v"(b.l[8]), "v"(b.l[7]), "v"(b.l[6]), "v"(b.l[5]), "v"(b.l[4]), "v"(b.l[3]), "v"(b.l[2]), "v"(b.l[1]), "v"(b.l[0]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %9, %0\n\tv_mad_u64_u32 %0, vcc, %2, %10, %0\n\tv_mad_u64_u32 %0, vcc, %3, %11, %0\n\tv_mad_u64_u32 %0, vcc, %4, %12, %0\n\tv_mad_u64_u32 %0, vcc, %5, %13, %0\n\tv_mad_u64_u32 %0, vcc, %6, %14, %0\n\tv_mad_u64_u32 %0, vcc, %7, %15, %0\n\tv_mad_u64_u32 %0, vcc, %8, %16, %0" : "+v"(acc) : "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "s"(PL[8]), "s"(PL[7]), "s"(PL[6]), "s"(PL[5]), "s"(PL[4]), "s"(PL[3]), "s"(PL[2]), "s"(PL[1]) : "vcc");
+  m[8] = mdig24((u32)acc); acc = mad(m[8], PL[0], acc); acc >>= 29;
+  asm("v_mad_u64_u32 %0, vcc, %1, %9, %0\n\tv_mad_u64_u32 %0, vcc, %2, %10, %0\n\tv_mad_u64_u32 %0, vcc, %3, %11, %0\n\tv_mad_u64_u32 %0, vcc, %4, %12, %0\n\tv_mad_u64_u32 %0, vcc, %5, %13, %0\n\tv_mad_u64_u32 %0, vcc, %6, %14, %0\n\tv_mad_u64_u32 %0, vcc, %7, %15, %0\n\tv_mad_u64_u32 %0, vcc, %8, %16, %0" : "+v"(acc) : "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]), "v"(a.l[8]), "v"(b.l[8]), "v"(b.l[7]), "v"(b.l[6]), "v"(b.l[5]), "v"(b.l[4]), "v"(b.l[3]), "v"(b.l[2]), "v"(b.l[1]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %9, %0\n\tv_mad_u64_u32 %0, vcc, %2, %10, %0\n\tv_mad_u64_u32 %0, vcc, %3, %11, %0\n\tv_mad_u64_u32 %0, vcc, %4, %12, %0\n\tv_mad_u64_u32 %0, vcc, %5, %13, %0\n\tv_mad_u64_u32 %0, vcc, %6, %14, %0\n\tv_mad_u64_u32 %0, vcc, %7, %15, %0\n\tv_mad_u64_u32 %0, vcc, %8, %16, %0" : "+v"(acc) : "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "s"(PL[8]), "s"(PL[7]), "s"(PL[6]), "s"(PL[5]), "s"(PL[4]), "s"(PL[3]), "s"(PL[2]), "s"(PL[1]) : "vcc");
+  r.l[0] = (u32)acc & MASK; acc >>= 29;
+  asm("v_mad_u64_u32 %0, vcc, %1, %8, %0\n\tv_mad_u64_u32 %0, vcc, %2, %9, %0\n\tv_mad_u64_u32 %0, vcc, %3, %10, %0\n\tv_mad_u64_u32 %0, vcc, %4, %11, %0\n\tv_mad_u64_u32 %0, vcc, %5, %12, %0\n\tv_mad_u64_u32 %0, vcc, %6, %13, %0\n\tv_mad_u64_u32 %0, vcc, %7, %14, %0" : "+v"(acc) : "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]), "v"(a.l[8]), "v"(b.l[8]), "v"(b.l[7]), "v"(b.l[6]), "v"(b.l[5]), "v"(b.l[4]), "v"(b.l[3]), "v"(b.l[2]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %8, %0\n\tv_mad_u64_u32 %0, vcc, %2, %9, %0\n\tv_mad_u64_u32 %0, vcc, %3, %10, %0\n\tv_mad_u64_u32 %0, vcc, %4, %11, %0\n\tv_mad_u64_u32 %0, vcc, %5, %12, %0\n\tv_mad_u64_u32 %0, vcc, %6, %13, %0\n\tv_mad_u64_u32 %0, vcc, %7, %14, %0" : "+v"(acc) : "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "s"(PL[8]), "s"(PL[7]), "s"(PL[6]), "s"(PL[5]), "s"(PL[4]), "s"(PL[3]), "s"(PL[2]) : "vcc");
+  r.l[1] = (u32)acc & MASK; acc >>= 29;
+  asm("v_mad_u64_u32 %0, vcc, %1, %7, %0\n\tv_mad_u64_u32 %0, vcc, %2, %8, %0\n\tv_mad_u64_u32 %0, vcc, %3, %9, %0\n\tv_mad_u64_u32 %0, vcc, %4, %10, %0\n\tv_mad_u64_u32 %0, vcc, %5, %11, %0\n\tv_mad_u64_u32 %0, vcc, %6, %12, %0" : "+v"(acc) : "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]), "v"(a.l[8]), "v"(b.l[8]), "v"(b.l[7]), "v"(b.l[6]), "v"(b.l[5]), "v"(b.l[4]), "v"(b.l[3]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %7, %0\n\tv_mad_u64_u32 %0, vcc, %2, %8, %0\n\tv_mad_u64_u32 %0, vcc, %3, %9, %0\n\tv_mad_u64_u32 %0, vcc, %4, %10, %0\n\tv_mad_u64_u32 %0, vcc, %5, %11, %0\n\tv_mad_u64_u32 %0, vcc, %6, %12, %0" : "+v"(acc) : "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "s"(PL[8]), "s"(PL[7]), "s"(PL[6]), "s"(PL[5]), "s"(PL[4]), "s"(PL[3]) : "vcc");
+  r.l[2] = (u32)acc & MASK; acc >>= 29;
+  asm("v_mad_u64_u32 %0, vcc, %1, %6, %0\n\tv_mad_u64_u32 %0, vcc, %2, %7, %0\n\tv_mad_u64_u32 %0, vcc, %3, %8, %0\n\tv_mad_u64_u32 %0, vcc, %4, %9, %0\n\tv_mad_u64_u32 %0, vcc, %5, %10, %0" : "+v"(acc) : "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]), "v"(a.l[8]), "v"(b.l[8]), "v"(b.l[7]), "v"(b.l[6]), "v"(b.l[5]), "v"(b.l[4]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %6, %0\n\tv_mad_u64_u32 %0, vcc, %2, %7, %0\n\tv_mad_u64_u32 %0, vcc, %3, %8, %0\n\tv_mad_u64_u32 %0, vcc, %4, %9, %0\n\tv_mad_u64_u32 %0, vcc, %5, %10, %0" : "+v"(acc) : "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "s"(PL[8]), "s"(PL[7]), "s"(PL[6]), "s"(PL[5]), "s"(PL[4]) : "vcc");
+  r.l[3] = (u32)acc & MASK; acc >>= 29;
+  asm("v_mad_u64_u32 %0, vcc, %1, %5, %0\n\tv_mad_u64_u32 %0, vcc, %2, %6, %0\n\tv_mad_u64_u32 %0, vcc, %3, %7, %0\n\tv_mad_u64_u32 %0, vcc, %4, %8, %0" : "+v"(acc) : "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]), "v"(a.l[8]), "v"(b.l[8]), "v"(b.l[7]), "v"(b.l[6]), "v"(b.l[5]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %5, %0\n\tv_mad_u64_u32 %0, vcc, %2, %6, %0\n\tv_mad_u64_u32 %0, vcc, %3, %7, %0\n\tv_mad_u64_u32 %0, vcc, %4, %8, %0" : "+v"(acc) : "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "s"(PL[8]), "s"(PL[7]), "s"(PL[6]), "s"(PL[5]) : "vcc");
+  r.l[4] = (u32)acc & MASK; acc >>= 29;
+  asm("v_mad_u64_u32 %0, vcc, %1, %4, %0\n\tv_mad_u64_u32 %0, vcc, %2, %5, %0\n\tv_mad_u64_u32 %0, vcc, %3, %6, %0" : "+v"(acc) : "v"(a.l[6]), "v"(a.l[7]), "v"(a.l[8]), "v"(b.l[8]), "v"(b.l[7]), "v"(b.l[6]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %4, %0\n\tv_mad_u64_u32 %0, vcc, %2, %5, %0\n\tv_mad_u64_u32 %0, vcc, %3, %6, %0" : "+v"(acc) : "v"(m[6]), "v"(m[7]), "v"(m[8]), "s"(PL[8]), "s"(PL[7]), "s"(PL[6]) : "vcc");
+  r.l[5] = (u32)acc & MASK; acc >>= 29;
+  asm("v_mad_u64_u32 %0, vcc, %1, %3, %0\n\tv_mad_u64_u32 %0, vcc, %2, %4, %0" : "+v"(acc) : "v"(a.l[7]), "v"(a.l[8]), "v"(b.l[8]), "v"(b.l[7]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %3, %0\n\tv_mad_u64_u32 %0, vcc, %2, %4, %0" : "+v"(acc) : "v"(m[7]), "v"(m[8]), "s"(PL[8]), "s"(PL[7]) : "vcc");
+  r.l[6] = (u32)acc & MASK; acc >>= 29;
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a.l[8]), "v"(b.l[8]) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(m[8]), "s"(PL[8]) : "vcc");
+  r.l[7] = (u32)acc & MASK; acc >>= 29;
+  r.l[8]=(u32)acc;
+  return r;
+}
 template<int V> __device__ __forceinline__ Fe mulv(const Fe& a, const Fe& b){
   if constexpr (V==0) return mul_A(a,b);
   else if constexpr (V==1) return mul_BC<false>(a,b);
   else if constexpr (V==2) return mul_BC<true>(a,b);
-  else return mul_E(a,b);
+  else if constexpr (V==3) return mul_E(a,b);
+  else if constexpr (V==4) return mul_F(a,b);
+  else if constexpr (V==5) return mul_G(a,b);
+  else return mul_H(a,b);
 }
 // NCH independent chains per lane; dynamic LDS request limits the occupancy to WPS waves per SIMD
 template<int V, int NCH>
@@ -172,20 +356,26 @@ int main(){
   int CU=prop.multiProcessorCount;
   u64 *o0,*o1; hipMalloc(&o0, sizeof(u64)*CU*16*256); hipMalloc(&o1, sizeof(u64)*CU*16*256);
   // parity of the variants (same inputs -> same checksum words)
-  u64 h[4][256];
-  for(int v=0;v<4;v++){
+  u64 h[7][256];
+  for(int v=0;v<7;v++){
     if(v==0) hipLaunchKernelGGL((k_mont<0,1>), dim3(1), dim3(256), 0, 0, o0, 12345u, 678u, 7);
     if(v==1) hipLaunchKernelGGL((k_mont<1,1>), dim3(1), dim3(256), 0, 0, o0, 12345u, 678u, 7);
     if(v==2) hipLaunchKernelGGL((k_mont<2,1>), dim3(1), dim3(256), 0, 0, o0, 12345u, 678u, 7);
     if(v==3) hipLaunchKernelGGL((k_mont<3,1>), dim3(1), dim3(256), 0, 0, o0, 12345u, 678u, 7);
+    if(v==4) hipLaunchKernelGGL((k_mont<4,1>), dim3(1), dim3(256), 0, 0, o0, 12345u, 678u, 7);
+    if(v==5) hipLaunchKernelGGL((k_mont<5,1>), dim3(1), dim3(256), 0, 0, o0, 12345u, 678u, 7);
+    if(v==6) hipLaunchKernelGGL((k_mont<6,1>), dim3(1), dim3(256), 0, 0, o0, 12345u, 678u, 7);
     hipMemcpy(h[v], o0, sizeof(u64)*256, hipMemcpyDeviceToHost);
   }
-  int bad=0; for(int i=0;i<256;i++) if(h[0][i]!=h[1][i]||h[0][i]!=h[2][i]||h[0][i]!=h[3][i]) bad++;
+  int bad=0; for(int i=0;i<256;i++) { for(int v=1;v<7;v++) if(h[0][i]!=h[v][i]) { bad++; break; } }
   printf("variant parity: %s\n", bad? "MISMATCH":"ok");
   run<0,1>("A plain C", o0, CU);
   run<1,1>("B chained carry", o0, CU);
   run<2,1>("C chained + alignbit", o0, CU);
   run<3,1>("E per-column asm chains", o0, CU);
+  run<4,1>("F = E, 32-bit shifts", o0, CU);
+  run<5,1>("G = F, 24-bit m digit", o0, CU);
+  run<6,1>("H = E, 24-bit m digit", o0, CU);
   run<0,2>("A plain C", o0, CU);
   run<1,2>("B chained carry", o0, CU);
   run<2,2>("C chained + alignbit", o0, CU);
