@@ -58,7 +58,12 @@ int staged_d2h_gated(HostCtx* c, void* h_dst, const void* d_src, size_t bytes, h
 struct CtxGuard {  // release on scope exit
   HostCtx* c = nullptr;
   ~CtxGuard() {
-    if (c) ctx_release(c);
+    if (!c) return;
+    // an entry point that fails half way may leave work queued that still uses the arena or the staging ring:
+    // nothing of a context is handed to the next caller before its streams have drained (idle streams: ~us)
+    for (auto& s : c->st)
+      if (s) hipStreamSynchronize(s);
+    ctx_release(c);
   }
 };
 

@@ -102,3 +102,49 @@ def test_field_batch_mul():
     m = rng.randrange(o.R)
     got = fb.field_batch_msm_native_helper(b"".join(o.to_le32(x) for x in xs + [m]), len(xs), 0)
     assert got == b"".join(int(x * m % o.R).to_bytes(64, "big") for x in xs)
+
+
+@pytest.mark.parametrize("bn,compact", [(1, 0), (1, 1), (2, 0), (2, 1)])
+def test_fixed_base_host_ranges_equal_one_range(bn, compact, monkeypatch):
+    """The host entry points compute the per-scalar part in ranges and download range by range behind the
+    computation (OZK_FB_HOST_RANGES): the bytes do not depend on the number of ranges, and sampled elements
+    equal the oracle's."""
+    import ctypes
+    import numpy as np
+    from octopuszk_amd import lib
+    L = lib.load()
+    n, w, outerc = 40000 + 7 * bn, 11, 24
+    rng = np.random.default_rng(bn * 2 + compact)
+    sc = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    sc[:, 31] &= 0x1F
+    G = o.G1 if bn == 1 else o.G2
+    base = G.mul(G.one, 0x1234567 + compact)
+    bw = np.frombuffer(o.g1_to_wire(base) if bn == 1 else o.g2_to_wire(base), dtype=np.uint8)
+    per = (192 if bn == 1 else 384) // (2 if compact else 1)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    outs = {}
+    try:
+        for k in (1, 4, 9):
+            monkeypatch.setenv("OZK_FB_HOST_RANGES", str(k))
+            lib.check(L.ozk_tuning_reload())
+            out = np.zeros(n * per, dtype=np.uint8)
+            if compact:
+                lib.check(L.ozk_fixed_batch_msm_compact_host(outerc, w, n, vp(bw), vp(sc), bn, 0, vp(out)))
+            else:
+                lib.check(L.ozk_fixed_batch_msm_host(outerc, w, outerc, 1 << w, n, 254, vp(bw), vp(sc), bn, 0, vp(out)))
+            outs[k] = out.tobytes()
+    finally:
+        monkeypatch.delenv("OZK_FB_HOST_RANGES", raising=False)
+        lib.check(L.ozk_tuning_reload())
+    assert outs[1] == outs[4] == outs[9]
+    cw = 32 if compact else 64
+    for i in (0, n // 2 + 1, n - 1):
+        s = int.from_bytes(sc[i].tobytes(), "little") % o.R
+        want = G.to_affine(G.mul(base, s))
+        rec = outs[4][i * per:(i + 1) * per]
+        if bn == 1:
+            got = [int.from_bytes(rec[j * cw:(j + 1) * cw], "little" if compact else "big") for j in range(2)]
+            assert (got[0], got[1]) == (want[0], want[1]), i
+        else:
+            got = [int.from_bytes(rec[j * cw:(j + 1) * cw], "little" if compact else "big") for j in range(4)]
+            assert ((got[0], got[1]), (got[2], got[3])) == (want[0], want[1]), i
