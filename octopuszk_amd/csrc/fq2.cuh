@@ -232,10 +232,10 @@ __device__ __forceinline__ Fe2<B> shfl_down_el(const Fe2<B>& v, int o) {
 
 // G2 over Fq2.  Loop-carried bounds: mul / sqr return < 2p, so the madd outputs are
 // X3 = sqr - (J + 2V) < 2p + 7p, Y3 < 2p + 5p, Z3 < 2p + 5p.
-struct G2CfgL;
+struct G2CfgO;
 struct G2Cfg {
-  using Pair = G2CfgL;                    // serial chains (Horner, fixed-base doubling chain) on a lane pair
-  static constexpr int PAIR_LANES = 2;
+  using Pair = G2CfgO;                    // serial chains (Horner, fixed-base doubling chain) on a lane OCTET
+  static constexpr int PAIR_LANES = 8;    // (below; a lane PAIR until round 2)
   static constexpr bool LDS_ACC = true;   // level-1 accumulator in LDS (msm_var.cuh RunAccLds)
   using EX = Fe2<144>;
   using EY = Fe2<112>;
@@ -254,7 +254,7 @@ struct G2Cfg {
 // Fe2L is the same element held IDENTICALLY by two adjacent lanes (an even / odd pair): the two Fq
 // products of a squaring, and two of the three of a Karatsuba multiplication, run side by side, one per
 // lane, and are exchanged with one __shfl_xor per limb; everything else is computed redundantly, so the
-// pair never diverges.  The generic group law (ec.cuh) runs unchanged over G2CfgL.
+// pair never diverges.
 template <int B>
 struct Fe2L {
   Fe<FqParams, B> c0, c1;
@@ -378,25 +378,179 @@ template <int B1, int B2, int B3, int B4>
 __device__ __forceinline__ auto mulsub(const Fe2L<B1>& a, const Fe2L<B2>& b, const Fe2L<B3>& c, const Fe2L<B4>& d) {
   return sub(mul(a, b), mul(c, d));
 }
-struct G2CfgL {
+// ---------------------------------------------------------------- G2 on a lane OCTET
+// The serial chains of G2 (Horner over the windows, the fixed-base doubling chain) on FOUR lane pairs: as on G1's
+// lane quad (quad.cuh) all eight lanes hold the same point, at every level of the formula pair k multiplies the k-th
+// operand pair (each product itself split over the two lanes of the pair, as above), and the four products come
+// back to all lanes through one cross-lane read per limb.  A doubling is three Fq2 multiplication times deep instead
+// of seven in a row, an addition five instead of sixteen: k_finalize<G2> 1.75 -> 1.48 ms, k_fb_chain<G2> 1.37 -> 1.04 ms
+// (a level costs an Fq2 product, ~3.6 k cycles on a pair, plus as much again in selects, 72 cross-lane reads and the
+// conditional subtractions that bring operands back under the squaring's input bound).
+struct G2CfgO {
   using EX = Fe2L<144>;
   using EY = Fe2L<112>;
   using EZ = Fe2L<112>;
 };
-__device__ __forceinline__ Jac<G2CfgL> to_pair(const Jac<G2Cfg>& p) {
-  Jac<G2CfgL> r;
+__device__ __forceinline__ Jac<G2CfgO> to_pair(const Jac<G2Cfg>& p) {
+  Jac<G2CfgO> r;
   r.X = to_pair(p.X);
   r.Y = to_pair(p.Y);
   r.Z = to_pair(p.Z);
   return r;
 }
-__device__ __forceinline__ Jac<G2Cfg> from_pair(const Jac<G2CfgL>& p) {
+__device__ __forceinline__ Jac<G2Cfg> from_pair(const Jac<G2CfgO>& p) {
   Jac<G2Cfg> r;
   r.X = from_pair(p.X);
   r.Y = from_pair(p.Y);
   r.Z = from_pair(p.Z);
   return r;
 }
+template <int B>
+__device__ __forceinline__ Fe2L<B> select_el(bool c, const Fe2L<B>& a, const Fe2L<B>& b) {
+  Fe2L<B> r;
+  r.c0 = select_el(c, a.c0, b.c0);
+  r.c1 = select_el(c, a.c1, b.c1);
+  return r;
+}
+// the value held by pair K of this lane's octet (same parity of lane: both lanes of a pair hold the same element)
+template <int K, int B>
+__device__ __forceinline__ Fe2L<B> octet_bcast(const Fe2L<B>& v) {
+  const int src = ((int)threadIdx.x & ~7) | (2 * K) | ((int)threadIdx.x & 1);
+  Fe2L<B> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    r.c0.l[i] = __shfl(v.c0.l[i], src);
+    r.c1.l[i] = __shfl(v.c1.l[i], src);
+  }
+  return r;
+}
+// out[k] = a[k] * b[k], k < 4, in ONE Fq2 multiplication time: pair k computes product k
+template <int BA, int BB>
+__device__ __forceinline__ void octet_mul4(const Fe2L<BA> (&a)[4], const Fe2L<BB> (&b)[4], Fe2L<32> (&out)[4]) {
+  const int role = ((int)threadIdx.x >> 1) & 3;
+  Fe2L<BA> x = a[0];
+  Fe2L<BB> y = b[0];
+#pragma unroll
+  for (int k = 1; k < 4; k++) {
+    x = select_el(role == k, a[k], x);
+    y = select_el(role == k, b[k], y);
+  }
+  const Fe2L<32> r = mul(x, y);
+  out[0] = octet_bcast<0>(r);
+  out[1] = octet_bcast<1>(r);
+  out[2] = octet_bcast<2>(r);
+  out[3] = octet_bcast<3>(r);
+}
+template <int BA>
+__device__ __forceinline__ void octet_sqr4(const Fe2L<BA> (&a)[4], Fe2L<32> (&out)[4]) {
+  const int role = ((int)threadIdx.x >> 1) & 3;
+  Fe2L<BA> x = a[0];
+#pragma unroll
+  for (int k = 1; k < 4; k++) x = select_el(role == k, a[k], x);
+  const Fe2L<32> r = sqr(x);
+  out[0] = octet_bcast<0>(r);
+  out[1] = octet_bcast<1>(r);
+  out[2] = octet_bcast<2>(r);
+  out[3] = octet_bcast<3>(r);
+}
+
+// dbl-2009-l (jac_dbl of ec.cuh) on an octet: three levels
+__device__ __forceinline__ Jac<G2CfgO> jac_dbl(const Jac<G2CfgO>& p) {
+  using F32 = Fe2L<32>;
+  const F32 X1 = reduce_to<32>(p.X), Y1 = reduce_to<32>(p.Y), Z1 = reduce_to<32>(p.Z);
+  F32 l1[4];
+  {
+    const F32 a[4] = {X1, Y1, Y1, Y1}, b[4] = {X1, Y1, Z1, Z1};
+    octet_mul4(a, b, l1);
+  }
+  const F32 A = l1[0], B = l1[1], YZ = l1[2];
+  const auto E = add(dbl(A), A);                                  // 3 X^2        (96)
+  F32 l2[4];
+  {
+    using F96 = Fe2L<96>;
+    const F96 a[4] = {F96(E), F96(B), F96(add(X1, B)), F96(B)};
+    octet_sqr4(a, l2);
+  }
+  const F32 F = l2[0], CC = l2[1], T = l2[2];
+  const auto t = reduce_to<32>(sub(T, add(A, CC)));
+  const auto D = dbl(t);
+  const auto X3 = reduce_to<32>(sub(F, dbl(D)));
+  const auto C8 = dbl(dbl(dbl(CC)));
+  const auto Y3 = sub(mul(E, reduce_to<48>(sub(D, X3))), C8);    // (the same product on all four pairs)
+  Jac<G2CfgO> r;
+  r.X = G2CfgO::EX(X3);
+  r.Y = G2CfgO::EY(reduce_to<64>(Y3));
+  r.Z = G2CfgO::EZ(dbl(YZ));
+  return r;
+}
+
+// add-2007-bl (jac_add of ec.cuh) on an octet: five levels
+__device__ __forceinline__ Jac<G2CfgO> jac_add(const Jac<G2CfgO>& p, const Jac<G2CfgO>& q) {
+  if (is_inf(p)) return q;   // (uniform over the octet: all eight lanes hold the same points)
+  if (is_inf(q)) return p;
+  using F32 = Fe2L<32>;
+  const F32 X1 = reduce_to<32>(p.X), Y1 = reduce_to<32>(p.Y), Z1 = reduce_to<32>(p.Z);
+  const F32 X2 = reduce_to<32>(q.X), Y2 = reduce_to<32>(q.Y), Z2 = reduce_to<32>(q.Z);
+  F32 l1[4];
+  {
+    const F32 a[4] = {Z1, Z2, Y1, Y2}, b[4] = {Z1, Z2, Z2, Z1};
+    octet_mul4(a, b, l1);
+  }
+  const F32 Z1Z1 = l1[0], Z2Z2 = l1[1], Y1Z2 = l1[2], Y2Z1 = l1[3];
+  F32 l2[4];
+  {
+    const F32 a[4] = {X1, X2, Y1Z2, Y2Z1}, b[4] = {Z2Z2, Z1Z1, Z2Z2, Z1Z1};
+    octet_mul4(a, b, l2);
+  }
+  const F32 U1 = l2[0], U2 = l2[1], S1 = l2[2], S2 = l2[3];
+  const auto H = sub(U2, U1);
+  const auto rh = sub(S2, S1);
+  if (is_zero(H)) {
+    if (is_zero(rh)) return jac_dbl(p);
+    return jac_infinity<G2CfgO>();
+  }
+  const auto H2 = dbl(H);
+  const auto r = dbl(rh);
+  const auto ZS = add(Z1, Z2);
+  using F3 = Fe2L<160>;
+  static_assert(std::is_convertible<decltype(H2), F3>::value && std::is_convertible<decltype(r), F3>::value &&
+                    std::is_convertible<decltype(ZS), F3>::value, "level-3 operand bound");
+  F32 l3[4];
+  {
+    const F3 a[4] = {F3(H2), F3(r), F3(ZS), F3(ZS)};
+    octet_sqr4(a, l3);
+  }
+  const F32 I = l3[0], RR = l3[1], ZZ = l3[2];
+  const auto Zd = reduce_to<80>(sub(ZZ, add(Z1Z1, Z2Z2)));
+  using F4 = Fe2L<80>;
+  static_assert(std::is_convertible<decltype(Zd), F4>::value && std::is_convertible<decltype(H), F4>::value,
+                "level-4 operand bound");
+  F32 l4[4];
+  {
+    const F4 a[4] = {F4(H), F4(U1), F4(Zd), F4(Zd)};
+    const F4 b[4] = {F4(I), F4(I), F4(H), F4(H)};
+    octet_mul4(a, b, l4);
+  }
+  const F32 J = l4[0], V = l4[1], Z3 = l4[2];
+  const auto X3 = reduce_to<64>(sub(RR, add(J, dbl(V))));
+  F32 l5[4];                                                     // Y3 = r (V - X3) - 2 S1 J: both products at once
+  {
+    using F5A = Fe2L<160>;
+    using F5B = Fe2L<112>;
+    const auto VX = sub(V, X3);
+    static_assert(std::is_convertible<decltype(VX), F5B>::value && std::is_convertible<decltype(r), F5A>::value &&
+                      lazy_ok(160, 112), "level-5 operand bound");
+    const F5A a[4] = {F5A(r), F5A(dbl(S1)), F5A(r), F5A(r)};
+    const F5B b[4] = {F5B(VX), F5B(J), F5B(VX), F5B(VX)};
+    octet_mul4(a, b, l5);
+  }
+  Jac<G2CfgO> out;
+  out.X = G2CfgO::EX(X3);
+  out.Y = G2CfgO::EY(sub(l5[0], l5[1]));
+  out.Z = G2CfgO::EZ(Z3);
+  return out;
+}
+
 template <class CV>
 __device__ __forceinline__ const Jac<CV>& to_pair(const Jac<CV>& p) { return p; }   // one-lane curves: identity
 template <class CV>
