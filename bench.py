@@ -109,9 +109,9 @@ def main():
                     help="pipeline (default): one head stream + one tail stream with the launch-order hint "
                          "(device.VarMsmPipeline) — the level-1 kernel runs alone, so its HIP-event duration is the "
                          "kernel's own; streams: complete MSMs issued round-robin on independent streams, the way "
-                         "concurrent prover threads drive the JNI — ~6 %% more throughput at 3 in flight (540-550 "
-                         "Mscalar-mul/s), but the overlapping level-1 kernels stretch each other's duration, which "
-                         "would distort `roofline`")
+                         "concurrent prover threads drive the JNI — 5-8 %% more throughput at 3 in flight (590-620 "
+                         "Mscalar-mul/s; the default run reports it as a secondary figure), but the overlapping level-1 "
+                         "kernels stretch each other's duration, which would distort `roofline`")
     args = ap.parse_args()
     if args.in_flight is None:
         args.in_flight = 3 if args.schedule == "streams" else 2
