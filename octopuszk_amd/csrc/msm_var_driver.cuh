@@ -73,14 +73,17 @@ static MsmPlan make_plan(int n) {
   p.sd = p.glv && c >= 2 && env_int("OZK_MSM_SIGNED", 1) != 0;
   p.cb = c - p.sd;
   p.W = ((p.glv ? 128 : 256) + c - 1) / c;
-  // entries per level-1 lane: 40 at 2^20 (64 entries per bucket: a bucket is cut into 2-3 pieces, which
+  // entries per level-1 lane: 56 at 2^20 (64 entries per bucket: a bucket is cut into ~2 pieces, which
   // the run merge sums).  Buckets grow with n; at a fixed 40 a 2^23 MSM cut every bucket into 26 pieces
   // (more than RUN_MAX: everything fell through to the generic levels, +1.4 ms) and a 2^22 one into 13
   // (run merge 1.3 ms of 11.4).  Keep ~3-4 pieces per bucket.
   {
     const long long per_bucket = (long long)p.n >> p.cb;  // entries per bucket and window
     long long l1 = per_bucket * 5 / 16;
-    if (l1 < 40) l1 = 40;
+    // at least 40 entries per lane; 56 from 2^20 points on (fewer pieces for the run merge: pipelined 2^20 G1 +1.5 %,
+    // G2 2^20 -0.15 ms, a 2^20-constraint proof -0.3 ms; smaller MSMs lose 30-100 us with it)
+    const long long l1_min = env_int("OZK_MSM_L1_MIN", p.n >= (1 << 20) ? 56 : 40);
+    if (l1 < l1_min) l1 = l1_min;
     if (l1 > 1024) l1 = 1024;
     p.L1 = env_int("OZK_MSM_L1", (int)l1);
   }
