@@ -157,7 +157,7 @@ __device__ __forceinline__ void store_be_coord(const Fe2<B>& e, u32* p) {
 }
 
 constexpr int FB_BATCH = 8;
-// lane t normalises results [t*FB_BATCH, ...): prefix products of Z, one inversion, back-substitution.
+// lane t normalises FB_BATCH results: prefix products of Z, one inversion, back-substitution.
 // out element i is at out + i*out_stride_words (+ coordinate offsets).
 // compact = 1: X|Y|Z as 32-byte little-endian values (the wire-IN format of the variable-base natives,
 // VariableBaseMSM.java:221-228), so that keys go from the setup to the prover without being reformatted
@@ -171,16 +171,20 @@ __global__ void __launch_bounds__(256) k_fb_norm(const u32* __restrict__ jac, in
   using EZ32 = decltype(reduce_to<32>(typename CV::EZ()));
   constexpr int OW = 2 * ET::WORDS;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int lo = t * FB_BATCH;
-  if (lo >= n) return;
-  const int cnt = (n - lo < FB_BATCH) ? (n - lo) : FB_BATCH;
+  const int lanes = (n + FB_BATCH - 1) / FB_BATCH;
+  if (t >= lanes) return;
+  // the lane's batch is INTERLEAVED — elements t, t + lanes, t + 2 lanes, ... — so that consecutive lanes touch
+  // consecutive records (any grouping serves Montgomery's trick; consecutive elements per lane made every access
+  // a 100-B record at a 864-B stride).  k_fb_norm 216 -> 203 us at 2^20: the kernel is bound by its 2^17 safegcd
+  // inversions (45 % of its instructions), not by these accesses.
+  auto at = [&](int k) { return (size_t)k * (size_t)lanes + (size_t)t; };
   // prefix[k] = product of the non-zero Z_0..Z_k
   EZ32 prefix[FB_BATCH];
   EZ32 run = EZ32(el_one(prefix[0]));
 #pragma unroll
   for (int k = 0; k < FB_BATCH; k++) {
-    if (k < cnt) {
-      const auto Z = reduce_to<32>(ElemTraits<typename CV::EZ>::load_raw(jac + (size_t)(lo + k) * IO::JAC_WORDS + 2 * IO::RW));
+    if (at(k) < (size_t)n) {
+      const auto Z = reduce_to<32>(ElemTraits<typename CV::EZ>::load_raw(jac + at(k) * IO::JAC_WORDS + 2 * IO::RW));
       if (!is_zero(Z)) run = EZ32(mul(run, Z));
     }
     prefix[k] = run;
@@ -188,9 +192,9 @@ __global__ void __launch_bounds__(256) k_fb_norm(const u32* __restrict__ jac, in
   EZ32 invrun = EZ32(inv(run));
 #pragma unroll
   for (int k = FB_BATCH - 1; k >= 0; k--) {
-    if (k < cnt) {
-      const Jac<CV> p = IO::load_jac(jac + (size_t)(lo + k) * IO::JAC_WORDS);
-      u32* o = out + (size_t)(lo + k) * out_stride_words;
+    if (at(k) < (size_t)n) {
+      const Jac<CV> p = IO::load_jac(jac + at(k) * IO::JAC_WORDS);
+      u32* o = out + at(k) * out_stride_words;
       const auto Z = reduce_to<32>(p.Z);
       if (is_zero(Z)) {  // (0, 1, 0), BNG1.java:163-166
         if (compact) {
@@ -234,15 +238,19 @@ __global__ void __launch_bounds__(256) k_fb_table_affine(const u32* __restrict__
   using EA = typename CV::EA;
   using EZ32 = decltype(reduce_to<32>(typename CV::EZ()));
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int lo = t * FB_BATCH;
-  if (lo >= n) return;
-  const int cnt = (n - lo < FB_BATCH) ? (n - lo) : FB_BATCH;
+  const int lanes = (n + FB_BATCH - 1) / FB_BATCH;
+  if (t >= lanes) return;
+  // the lane's batch is INTERLEAVED — elements t, t + lanes, t + 2 lanes, ... — so that consecutive lanes touch
+  // consecutive records (any grouping serves Montgomery's trick; consecutive elements per lane made every access
+  // a 100-B record at a 864-B stride).  k_fb_norm 216 -> 203 us at 2^20: the kernel is bound by its 2^17 safegcd
+  // inversions (45 % of its instructions), not by these accesses.
+  auto at = [&](int k) { return (size_t)k * (size_t)lanes + (size_t)t; };
   EZ32 prefix[FB_BATCH];
   EZ32 run = EZ32(el_one(prefix[0]));
 #pragma unroll
   for (int k = 0; k < FB_BATCH; k++) {
-    if (k < cnt) {
-      const auto Z = reduce_to<32>(ElemTraits<typename CV::EZ>::load_raw(jac + (size_t)(lo + k) * IO::JAC_WORDS + 2 * IO::RW));
+    if (at(k) < (size_t)n) {
+      const auto Z = reduce_to<32>(ElemTraits<typename CV::EZ>::load_raw(jac + at(k) * IO::JAC_WORDS + 2 * IO::RW));
       if (!is_zero(Z)) run = EZ32(mul(run, Z));
     }
     prefix[k] = run;
@@ -250,8 +258,8 @@ __global__ void __launch_bounds__(256) k_fb_table_affine(const u32* __restrict__
   EZ32 invrun = EZ32(inv(run));
 #pragma unroll
   for (int k = FB_BATCH - 1; k >= 0; k--) {
-    if (k < cnt) {
-      const Jac<CV> p = IO::load_jac(jac + (size_t)(lo + k) * IO::JAC_WORDS);
+    if (at(k) < (size_t)n) {
+      const Jac<CV> p = IO::load_jac(jac + at(k) * IO::JAC_WORDS);
       const auto Z = reduce_to<32>(p.Z);
       Aff<EA> q;
       if (is_zero(Z)) {
@@ -265,7 +273,7 @@ __global__ void __launch_bounds__(256) k_fb_table_affine(const u32* __restrict__
         q.x = EA(reduce_to<17>(mul(p.X, zi2)));
         q.y = EA(reduce_to<17>(mul(p.Y, mul(zi2, zi))));
       }
-      IO::store_aff(q, aff + (size_t)(lo + k) * IO::AFF_WORDS);
+      IO::store_aff(q, aff + at(k) * IO::AFF_WORDS);
     }
   }
 }
