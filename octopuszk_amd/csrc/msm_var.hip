@@ -225,6 +225,36 @@ int ozk_var_double_msm_host(const uint8_t* bases_g1, const uint8_t* bases_g2, co
   int rc = ctx_acquire(task_id, &g.c);
   if (rc) return rc;
   HostCtx* c = g.c;
+  const int K = host_slices(n);
+  if (K > 1 && 2 * K <= MAX_SLICES) {
+    // Large call: the scalars go up once, then the G1 bases and the G2 bases slice by slice; each slice's sort +
+    // bucket accumulation is queued behind its upload (G1 on the first stream, G2 on the second), one tail per
+    // curve (var_msm_host's form) — the 288 n bytes of bases hide most of both accumulations.
+    const int per = (n + K - 1) / K;
+    const size_t padded = (size_t)K * per;
+    const size_t w1 = host_sliced_ws_bytes<G1Cfg>(K, per), w2 = host_sliced_ws_bytes<G2Cfg>(K, per);
+    if ((rc = ctx_reserve(c, pad256(padded * 32) + pad256(padded * 96) + pad256(padded * 192) + 1024 + w1 + w2 + 1024)))
+      return rc;
+    uint8_t* d_sc = c->arena;
+    uint8_t* d_b1 = d_sc + pad256(padded * 32);
+    uint8_t* d_b2 = d_b1 + pad256(padded * 96);
+    uint8_t* d_out = d_b2 + pad256(padded * 192);
+    uint8_t* d_w1 = d_out + 1024;
+    uint8_t* d_w2 = d_w1 + w1;
+    hipStream_t up = c->st[2];
+    if (padded > (size_t)n) OZK_HIP(hipMemsetAsync(d_sc + (size_t)n * 32, 0, (padded - n) * 32, up));
+    if ((rc = staged_h2d(c, d_sc, scalars, (size_t)n * 32, up))) return rc;
+    if ((rc = host_sliced_msm<G1Cfg>(c, bases_g1, nullptr, n, K, per, d_b1, d_sc, d_w1, d_out, c->slice_ev, c->st[0], up)))
+      return rc;
+    if ((rc = host_sliced_msm<G2Cfg>(c, bases_g2, nullptr, n, K, per, d_b2, d_sc, d_w2, d_out + 256, c->slice_ev + K,
+                                     c->st[1], up)))
+      return rc;
+    OZK_HIP(hipMemcpyAsync(out, d_out, 192, hipMemcpyDeviceToHost, c->st[0]));
+    OZK_HIP(hipMemcpyAsync(out + 192, d_out + 256, 384, hipMemcpyDeviceToHost, c->st[1]));
+    OZK_HIP(hipStreamSynchronize(c->st[0]));
+    OZK_HIP(hipStreamSynchronize(c->st[1]));
+    return OZK_OK;
+  }
   const size_t b1 = (size_t)n * 96, b2 = (size_t)n * 192, sc = (size_t)n * 32;
   const size_t w1 = var_msm_ws_bytes<G1Cfg>(n), w2 = var_msm_ws_bytes<G2Cfg>(n);
   if ((rc = ctx_reserve(c, pad256(b1) + pad256(b2) + pad256(sc) + 1024 + pad256(w1) + pad256(w2) + 1024))) return rc;

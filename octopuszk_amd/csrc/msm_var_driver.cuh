@@ -513,6 +513,51 @@ inline int host_slices(int n) {
   return k < 1 ? 1 : k;
 }
 
+// The sliced part of a host MSM, on a context the caller holds: K slices of `per` pairs (the last one padded).
+// d_bases / d_sc hold K * per records; `scalars` == nullptr: the caller has already queued the upload of ALL scalars
+// (and the zero padding) on `up`, so only the bases go up here.  Slice events ev[0 .. K).  Leaves the result
+// (wire-out) in d_out on `st`.
+template <class CV>
+size_t host_sliced_ws_bytes(int K, int per) {
+  return pad256(var_msm_head_ws_bytes<CV>(per)) + (size_t)K * pad256(var_msm_tail_bytes<CV>(per));
+}
+template <class CV>
+int host_sliced_msm(HostCtx* c, const uint8_t* bases, const uint8_t* scalars, int n, int K, int per, uint8_t* d_bases,
+                    uint8_t* d_sc, uint8_t* d_ws, uint8_t* d_out, hipEvent_t* ev, hipStream_t st, hipStream_t up) {
+  using IO = CurveIO<CV>;
+  const size_t base_rec = (size_t)IO::WIRE_JAC_WORDS * 4;
+  const size_t padded = (size_t)K * per;
+  const size_t main_bytes = pad256(var_msm_head_ws_bytes<CV>(per));
+  const size_t tb = pad256(var_msm_tail_bytes<CV>(per));
+  uint8_t* d_tails = d_ws + main_bytes;
+  int rc;
+  if (padded > (size_t)n) {
+    if (scalars) OZK_HIP(hipMemsetAsync(d_sc + (size_t)n * 32, 0, (padded - n) * 32, up));
+    OZK_HIP(hipMemsetAsync(d_bases + (size_t)n * base_rec, 0, (padded - n) * base_rec, up));  // Z = 0: infinity
+  }
+  const MsmPlan p = make_plan(per);
+  SliceBuckets sb = {};
+  for (int s = 0; s < K; s++) {
+    const size_t lo = (size_t)s * per;
+    const size_t ns = ((size_t)n - lo < (size_t)per) ? ((size_t)n - lo) : (size_t)per;
+    if (scalars && (rc = staged_h2d(c, d_sc + lo * 32, scalars + lo * 32, ns * 32, up))) return rc;
+    if ((rc = staged_h2d(c, d_bases + lo * base_rec, bases + lo * base_rec, ns * base_rec, up))) return rc;
+    OZK_HIP(hipEventRecord(ev[s], up));
+    OZK_HIP(hipStreamWaitEvent(st, ev[s], 0));
+    uint8_t* tail = d_tails + (size_t)s * tb;
+    if ((rc = var_msm_head<CV>(d_bases + lo * base_rec, d_sc + lo * 32, per, d_ws, main_bytes, tail, tb, st))) return rc;
+    MsmLayout L;
+    tail_layout<CV>(p, L, tail, tb);
+    sb.buckets[s] = L.buckets;
+    sb.hist[s] = L.hist_t;
+  }
+  const size_t NB = (size_t)p.W << p.cb;
+  hipLaunchKernelGGL((k_bucket_combine<CV>), dim3((unsigned)((NB + 255) / 256)), dim3(256), 0, st, sb, K,
+                     (u32*)sb.buckets[0], (u32*)sb.hist[0], NB);
+  OZK_HIP(hipGetLastError());
+  return var_msm_tail<CV>(per, d_tails, tb, d_out, st);
+}
+
 template <class CV>
 int var_msm_host(const uint8_t* bases, const uint8_t* scalars, int n, int task_id, uint8_t* out) {
   using IO = CurveIO<CV>;
@@ -539,42 +584,16 @@ int var_msm_host(const uint8_t* bases, const uint8_t* scalars, int n, int task_i
   }
   const int per = (n + K - 1) / K;               // every slice is planned and laid out for `per` pairs
   const size_t padded = (size_t)K * per;
-  const size_t main_bytes = pad256(var_msm_head_ws_bytes<CV>(per));
-  const size_t tb = pad256(var_msm_tail_bytes<CV>(per));
-  if ((rc = ctx_reserve(c, pad256(padded * base_rec) + pad256(padded * 32) + 1024 + main_bytes + (size_t)K * tb + 1024)))
+  if ((rc = ctx_reserve(c, pad256(padded * base_rec) + pad256(padded * 32) + 1024 + host_sliced_ws_bytes<CV>(K, per) + 1024)))
     return rc;
   uint8_t* d_bases = c->arena;
   uint8_t* d_sc = d_bases + pad256(padded * base_rec);
   uint8_t* d_out = d_sc + pad256(padded * 32);
   uint8_t* d_ws = d_out + 1024;
-  uint8_t* d_tails = d_ws + main_bytes;
-  hipStream_t st = c->st[0], up = c->st[2];  // uploads on their own queue: they must not wait behind kernels
-  if (padded > (size_t)n) {
-    OZK_HIP(hipMemsetAsync(d_sc + (size_t)n * 32, 0, (padded - n) * 32, up));
-    OZK_HIP(hipMemsetAsync(d_bases + (size_t)n * base_rec, 0, (padded - n) * base_rec, up));  // Z = 0: infinity
-  }
-  const MsmPlan p = make_plan(per);
-  SliceBuckets sb = {};
-  for (int s = 0; s < K; s++) {
-    const size_t lo = (size_t)s * per;
-    const size_t ns = ((size_t)n - lo < (size_t)per) ? ((size_t)n - lo) : (size_t)per;
-    if ((rc = staged_h2d(c, d_sc + lo * 32, scalars + lo * 32, ns * 32, up))) return rc;
-    if ((rc = staged_h2d(c, d_bases + lo * base_rec, bases + lo * base_rec, ns * base_rec, up))) return rc;
-    OZK_HIP(hipEventRecord(c->slice_ev[s], up));
-    OZK_HIP(hipStreamWaitEvent(st, c->slice_ev[s], 0));
-    uint8_t* tail = d_tails + (size_t)s * tb;
-    if ((rc = var_msm_head<CV>(d_bases + lo * base_rec, d_sc + lo * 32, per, d_ws, main_bytes, tail, tb, st))) return rc;
-    MsmLayout L;
-    tail_layout<CV>(p, L, tail, tb);
-    sb.buckets[s] = L.buckets;
-    sb.hist[s] = L.hist_t;
-  }
-  const size_t NB = (size_t)p.W << p.cb;
-  hipLaunchKernelGGL((k_bucket_combine<CV>), dim3((unsigned)((NB + 255) / 256)), dim3(256), 0, st, sb, K,
-                     (u32*)sb.buckets[0], (u32*)sb.hist[0], NB);
-  OZK_HIP(hipGetLastError());
-  if ((rc = var_msm_tail<CV>(per, d_tails, tb, d_out, st))) return rc;
-  return staged_d2h(c, out, d_out, out_bytes, st);
+  // uploads on the context's copy stream: they must not wait behind kernels
+  if ((rc = host_sliced_msm<CV>(c, bases, scalars, n, K, per, d_bases, d_sc, d_ws, d_out, c->slice_ev, c->st[0], c->st[2])))
+    return rc;
+  return staged_d2h(c, out, d_out, out_bytes, c->st[0]);
 }
 
 // ---- prepared bases: the affine Montgomery records (GLV: both halves) of a base
@@ -696,6 +715,10 @@ int bases_msm(BasesHandle* h, const uint8_t* scalars, uint8_t* out) {
   PREFIX template int ozk::var_msm_dev<ozk::G2Cfg>(const void*, const void*, int, void*, void*, size_t, hipStream_t,  \
                                                    const void*);                                                     \
   PREFIX template int ozk::var_msm_host<ozk::G2Cfg>(const uint8_t*, const uint8_t*, int, int, uint8_t*);             \
+  PREFIX template size_t ozk::host_sliced_ws_bytes<ozk::G2Cfg>(int, int);                                            \
+  PREFIX template int ozk::host_sliced_msm<ozk::G2Cfg>(ozk::HostCtx*, const uint8_t*, const uint8_t*, int, int, int, \
+                                                       uint8_t*, uint8_t*, uint8_t*, uint8_t*, hipEvent_t*,         \
+                                                       hipStream_t, hipStream_t);                                   \
   PREFIX template int ozk::var_msm_prepare<ozk::G2Cfg>(const void*, int, void*, size_t, hipStream_t);                \
   PREFIX template int ozk::bases_create<ozk::G2Cfg>(const uint8_t*, int, int, int, ozk::BasesHandle**);              \
   PREFIX template int ozk::bases_msm<ozk::G2Cfg>(ozk::BasesHandle*, const uint8_t*, uint8_t*);

@@ -176,3 +176,40 @@ def test_host_entry_sliced_upload_equals_single_slice(type_, n, min_log, monkeyp
     assert outs[8] == outs[1] == outs[3]
     if type_ == 1:
         assert outs[8] == coracle.pippenger_g1(bw.tobytes(), sc.tobytes(), n)
+
+
+@pytest.mark.parametrize("n,min_log", [(9001, 11), (70001, 14)])
+def test_double_msm_host_sliced_equals_two_single_calls(n, min_log, monkeypatch):
+    """ozk_var_double_msm_host above the slicing threshold: the scalars go up once, G1 and G2 bases slice by slice,
+    one tail per curve — the 576 bytes must be the G1 and the G2 result of the unsliced single calls."""
+    import ctypes
+    from octopuszk_amd import lib
+    L = lib.load()
+    rng = np.random.default_rng(n)
+    p1 = [o.G1.to_affine(o.G1.mul(o.G1.one, int(k))) for k in rng.integers(1, 1 << 62, size=16)]
+    p2 = [o.G2.to_affine(o.G2.mul(o.G2.one, int(k))) for k in rng.integers(1, 1 << 62, size=16)]
+    p1[3], p2[7] = o.G1.zero, o.G2.zero
+    pick = rng.integers(0, 16, size=n)
+    b1 = np.ascontiguousarray(np.stack([np.frombuffer(o.g1_to_wire(p), dtype=np.uint8) for p in p1])[pick]).reshape(-1)
+    b2 = np.ascontiguousarray(np.stack([np.frombuffer(o.g2_to_wire(p), dtype=np.uint8) for p in p2])[pick]).reshape(-1)
+    sc = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    sc[:, 31] &= 0x1F
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    try:
+        monkeypatch.setenv("OZK_HOST_SLICES", "1")
+        lib.check(L.ozk_tuning_reload())
+        one1, one2, dbl1 = np.zeros(192, dtype=np.uint8), np.zeros(384, dtype=np.uint8), np.zeros(576, dtype=np.uint8)
+        lib.check(L.ozk_var_msm_host(vp(b1), vp(sc), n, 1, 0, vp(one1)))
+        lib.check(L.ozk_var_msm_host(vp(b2), vp(sc), n, 2, 0, vp(one2)))
+        lib.check(L.ozk_var_double_msm_host(vp(b1), vp(b2), vp(sc), n, 0, vp(dbl1)))
+        monkeypatch.setenv("OZK_HOST_SLICES", "4")
+        monkeypatch.setenv("OZK_HOST_SLICE_MIN_LOG", str(min_log))
+        lib.check(L.ozk_tuning_reload())
+        dbl4 = np.zeros(576, dtype=np.uint8)
+        lib.check(L.ozk_var_double_msm_host(vp(b1), vp(b2), vp(sc), n, 0, vp(dbl4)))
+    finally:
+        monkeypatch.delenv("OZK_HOST_SLICES", raising=False)
+        monkeypatch.delenv("OZK_HOST_SLICE_MIN_LOG", raising=False)
+        lib.check(L.ozk_tuning_reload())
+    assert bytes(dbl1) == bytes(one1) + bytes(one2)
+    assert bytes(dbl4) == bytes(dbl1)
