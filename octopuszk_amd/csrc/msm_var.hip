@@ -230,7 +230,7 @@ int ozk_var_double_msm_host(const uint8_t* bases_g1, const uint8_t* bases_g2, co
     // Large call: the scalars go up once, then the G1 bases and the G2 bases slice by slice; each slice's sort +
     // bucket accumulation is queued behind its upload (G1 on the first stream, G2 on the second), one tail per
     // curve (var_msm_host's form) — the 288 n bytes of bases hide most of both accumulations.
-    const int per = (n + K - 1) / K;
+    const int per = host_slice_per(n, K);
     const size_t padded = (size_t)K * per;
     const size_t w1 = host_sliced_ws_bytes<G1Cfg>(K, per), w2 = host_sliced_ws_bytes<G2Cfg>(K, per);
     if ((rc = ctx_reserve(c, pad256(padded * 32) + pad256(padded * 96) + pad256(padded * 192) + 1024 + w1 + w2 + 1024)))
