@@ -383,7 +383,7 @@ __device__ __forceinline__ auto mulsub(const Fe2L<B1>& a, const Fe2L<B2>& b, con
 // lane quad (quad.cuh) all eight lanes hold the same point, at every level of the formula pair k multiplies the k-th
 // operand pair (each product itself split over the two lanes of the pair, as above), and the four products come
 // back to all lanes through one cross-lane read per limb.  A doubling is three Fq2 multiplication times deep instead
-// of seven in a row, an addition five instead of sixteen: k_finalize<G2> 1.75 -> 1.48 ms, k_fb_chain<G2> 1.37 -> 1.04 ms
+// of seven in a row, an addition five instead of sixteen: k_finalize<G2> 1.75 -> 1.31 ms, k_fb_chain<G2> 1.37 -> 0.90 ms
 // (a level costs an Fq2 product, ~3.6 k cycles on a pair, plus as much again in selects, 72 cross-lane reads and the
 // conditional subtractions that bring operands back under the squaring's input bound).
 struct G2CfgO {
@@ -457,10 +457,13 @@ __device__ __forceinline__ void octet_sqr4(const Fe2L<BA> (&a)[4], Fe2L<32> (&ou
 // dbl-2009-l (jac_dbl of ec.cuh) on an octet: three levels
 __device__ __forceinline__ Jac<G2CfgO> jac_dbl(const Jac<G2CfgO>& p) {
   using F32 = Fe2L<32>;
-  const F32 X1 = reduce_to<32>(p.X), Y1 = reduce_to<32>(p.Y), Z1 = reduce_to<32>(p.Z);
+  using FI = Fe2L<112>;          // Y and Z as they come (< 112 sixteenths of p: inside the lazy product's slack);
+  static_assert(lazy_ok(112, 112), "level-1 operand bound");
+  const F32 X1 = reduce_to<32>(p.X);   // X (< 144) is not, and X + Y^2 feeds a squaring (input < 2p)
+  const FI Y1 = FI(p.Y), Z1 = FI(p.Z);
   F32 l1[4];
   {
-    const F32 a[4] = {X1, Y1, Y1, Y1}, b[4] = {X1, Y1, Z1, Z1};
+    const FI a[4] = {FI(X1), Y1, Y1, Y1}, b[4] = {FI(X1), Y1, Z1, Z1};
     octet_mul4(a, b, l1);
   }
   const F32 A = l1[0], B = l1[1], YZ = l1[2];

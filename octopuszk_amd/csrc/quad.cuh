@@ -69,29 +69,34 @@ __device__ __forceinline__ void quad_mul4(const Fe<P, BA> (&a)[4], const Fe<P, B
   out[3] = quad_bcast<3>(r);
 }
 
-// dbl-2009-l on a quad (jac_dbl of ec.cuh, BNG1.java:133-161): three multiplication times
+// dbl-2009-l on a quad (jac_dbl of ec.cuh, BNG1.java:133-161): three multiplication times.
+// The bounds are left to grow where the multiplier's input slack takes them (B1 B2 <= 169 x 256: 96 x 96, 116 x 116
+// and 60 x 234 are far inside), so that only the two loop-carried coordinates X3, Y3 are brought back — four
+// conditional subtractions per doubling instead of the fifteen of the first version (which reduced every operand
+// to < 2p on entry): k_fb_chain (128 doublings) 455 -> 369 us, k_finalize 560 -> 530 us.
 __device__ __forceinline__ Jac<G1CfgQ> jac_dbl(const Jac<G1CfgQ>& p) {
-  using F32 = Fe<FqParams, 32>;
-  using F51 = Fe<FqParams, 51>;
-  const F32 X1 = reduce_to<32>(p.X), Y1 = reduce_to<32>(p.Y), Z1 = reduce_to<32>(p.Z);
-  decltype(mul(F32(), F32())) l1[4];
+  using FI = Fe<FqParams, 96>;   // the coordinates as they come: X < 94, Y < 73, Z < 78 (sixteenths of p)
+  const FI X1 = FI(p.X), Y1 = FI(p.Y), Z1 = FI(p.Z);
+  decltype(mul(FI(), FI())) l1[4];                                // < 20
   {
-    const F32 a[4] = {X1, Y1, Y1, Y1}, b[4] = {X1, Y1, Z1, Z1};
+    const FI a[4] = {X1, Y1, Y1, Y1}, b[4] = {X1, Y1, Z1, Z1};
     quad_mul4(a, b, l1);
   }
   const auto A = l1[0], B = l1[1], YZ = l1[2];
-  const auto E = add(dbl(A), A);                                  // 3 X^2
-  decltype(mul(F51(), F51())) l2[4];
+  const auto E = add(dbl(A), A);                                  // 3 X^2        (< 60)
+  using F2 = Fe<FqParams, 116>;
+  static_assert(std::is_convertible<decltype(add(X1, B)), F2>::value && std::is_convertible<decltype(E), F2>::value,
+                "level-2 operand bound");
+  decltype(mul(F2(), F2())) l2[4];                                // < 21
   {
-    const F51 a[4] = {F51(E), F51(B), F51(add(X1, B)), F51(B)};
+    const F2 a[4] = {F2(E), F2(B), F2(add(X1, B)), F2(B)};
     quad_mul4(a, a, l2);
   }
   const auto F = l2[0], CC = l2[1], T = l2[2];
-  const auto t = reduce_to<32>(sub(T, add(A, CC)));
-  const auto D = dbl(t);
-  const auto X3 = reduce_to<32>(sub(F, dbl(D)));
+  const auto D = dbl(sub(T, add(A, CC)));                         // 2 ((X + B)^2 - A - C)
+  const auto X3 = reduce_to<80>(sub(F, dbl(D)));
   const auto C8 = dbl(dbl(dbl(CC)));
-  const auto Y3 = sub(mul(E, reduce_to<48>(sub(D, X3))), C8);    // (the same product on all four lanes)
+  const auto Y3 = sub(mul(E, sub(D, X3)), C8);                    // (the same product on all four lanes)
   Jac<G1CfgQ> r;
   r.X = G1CfgQ::EX(X3);
   r.Y = G1CfgQ::EY(reduce_to<64>(Y3));
