@@ -236,6 +236,7 @@ struct G2CfgO;
 struct G2Cfg {
   using Pair = G2CfgO;                    // serial chains (Horner, fixed-base doubling chain) on a lane OCTET
   static constexpr int PAIR_LANES = 8;    // (below; a lane PAIR until round 2)
+  static constexpr bool WIDE_INPUTS = false;
   static constexpr bool LDS_ACC = true;   // level-1 accumulator in LDS (msm_var.cuh RunAccLds)
   using EX = Fe2<144>;
   using EY = Fe2<112>;
