@@ -298,12 +298,14 @@ template <class CV>
 OZK_HD Jac<CV> jac_add(const Jac<CV>& p, const Jac<CV>& q) {
   if (is_inf(p)) return q;
   if (is_inf(q)) return p;
-  const auto X1 = entry_reduce<48, CV>(p.X);
-  const auto Y1 = entry_reduce<48, CV>(p.Y);
-  const auto Z1 = entry_reduce<48, CV>(p.Z);
-  const auto X2 = entry_reduce<48, CV>(q.X);
-  const auto Y2 = entry_reduce<48, CV>(q.Y);
-  const auto Z2 = entry_reduce<48, CV>(q.Z);
+  // X and Y only ever meet a factor below 2p (Z^2, Z), which the lazy products of both fields take unreduced; Z is
+  // squared and added: the base field takes that too, Fq2's squaring wants it below 2p
+  const auto& X1 = p.X;
+  const auto& Y1 = p.Y;
+  const auto& X2 = q.X;
+  const auto& Y2 = q.Y;
+  const auto Z1 = entry_reduce<32, CV>(p.Z);
+  const auto Z2 = entry_reduce<32, CV>(q.Z);
   const auto Z1Z1 = sqr(Z1);
   const auto Z2Z2 = sqr(Z2);
   const auto U1 = mul(X1, Z2Z2);

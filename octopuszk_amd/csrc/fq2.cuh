@@ -493,17 +493,24 @@ __device__ __forceinline__ Jac<G2CfgO> jac_add(const Jac<G2CfgO>& p, const Jac<G
   if (is_inf(p)) return q;   // (uniform over the octet: all eight lanes hold the same points)
   if (is_inf(q)) return p;
   using F32 = Fe2L<32>;
-  const F32 X1 = reduce_to<32>(p.X), Y1 = reduce_to<32>(p.Y), Z1 = reduce_to<32>(p.Z);
-  const F32 X2 = reduce_to<32>(q.X), Y2 = reduce_to<32>(q.Y), Z2 = reduce_to<32>(q.Z);
+  using FY = Fe2L<112>;
+  using FX = Fe2L<144>;
+  static_assert(lazy_ok(112, 32) && lazy_ok(144, 32), "operand bounds of the first two levels");
+  // X and Y enter their products as they come (the other factor is < 2p); only Z, which is squared and added, is reduced
+  const FX X1 = FX(p.X), X2 = FX(q.X);
+  const FY Y1 = FY(p.Y), Y2 = FY(q.Y);
+  const F32 Z1 = reduce_to<32>(p.Z), Z2 = reduce_to<32>(q.Z);
   F32 l1[4];
   {
-    const F32 a[4] = {Z1, Z2, Y1, Y2}, b[4] = {Z1, Z2, Z2, Z1};
+    const FY a[4] = {FY(Z1), FY(Z2), Y1, Y2};
+    const F32 b[4] = {Z1, Z2, Z2, Z1};
     octet_mul4(a, b, l1);
   }
   const F32 Z1Z1 = l1[0], Z2Z2 = l1[1], Y1Z2 = l1[2], Y2Z1 = l1[3];
   F32 l2[4];
   {
-    const F32 a[4] = {X1, X2, Y1Z2, Y2Z1}, b[4] = {Z2Z2, Z1Z1, Z2Z2, Z1Z1};
+    const FX a[4] = {X1, X2, FX(Y1Z2), FX(Y2Z1)};
+    const F32 b[4] = {Z2Z2, Z1Z1, Z2Z2, Z1Z1};
     octet_mul4(a, b, l2);
   }
   const F32 U1 = l2[0], U2 = l2[1], S1 = l2[2], S2 = l2[3];

@@ -108,20 +108,20 @@ __device__ __forceinline__ Jac<G1CfgQ> jac_dbl(const Jac<G1CfgQ>& p) {
 __device__ __forceinline__ Jac<G1CfgQ> jac_add(const Jac<G1CfgQ>& p, const Jac<G1CfgQ>& q) {
   if (is_inf(p)) return q;   // (uniform over the quad: all four lanes hold the same points)
   if (is_inf(q)) return p;
-  using F48 = Fe<FqParams, 48>;
-  const F48 X1 = reduce_to<48>(p.X), Y1 = reduce_to<48>(p.Y), Z1 = reduce_to<48>(p.Z);
-  const F48 X2 = reduce_to<48>(q.X), Y2 = reduce_to<48>(q.Y), Z2 = reduce_to<48>(q.Z);
-  using FP = decltype(mul(F48(), F48()));
-  FP l1[4];
+  using FI = Fe<FqParams, 96>;   // the coordinates as they come (see jac_dbl above)
+  const FI X1 = FI(p.X), Y1 = FI(p.Y), Z1 = FI(p.Z);
+  const FI X2 = FI(q.X), Y2 = FI(q.Y), Z2 = FI(q.Z);
+  using FL1 = decltype(mul(FI(), FI()));                          // < 20
+  FL1 l1[4];
   {
-    const F48 a[4] = {Z1, Z2, Y1, Y2}, b[4] = {Z1, Z2, Z2, Z1};
+    const FI a[4] = {Z1, Z2, Y1, Y2}, b[4] = {Z1, Z2, Z2, Z1};
     quad_mul4(a, b, l1);
   }
   const auto Z1Z1 = l1[0], Z2Z2 = l1[1], Y1Z2 = l1[2], Y2Z1 = l1[3];
-  decltype(mul(F48(), FP())) l2[4];
+  decltype(mul(FI(), FL1())) l2[4];
   {
-    const F48 a[4] = {X1, X2, F48(Y1Z2), F48(Y2Z1)};
-    const FP b[4] = {Z2Z2, Z1Z1, Z2Z2, Z1Z1};
+    const FI a[4] = {X1, X2, FI(Y1Z2), FI(Y2Z1)};
+    const FL1 b[4] = {Z2Z2, Z1Z1, Z2Z2, Z1Z1};
     quad_mul4(a, b, l2);
   }
   const auto U1 = l2[0], U2 = l2[1], S1 = l2[2], S2 = l2[3];
@@ -134,7 +134,7 @@ __device__ __forceinline__ Jac<G1CfgQ> jac_add(const Jac<G1CfgQ>& p, const Jac<G
   const auto H2 = dbl(H);
   const auto r = dbl(rh);
   const auto ZS = add(Z1, Z2);
-  using F3 = Fe<FqParams, 98>;
+  using F3 = Fe<FqParams, 192>;
   static_assert(std::is_convertible<decltype(H2), F3>::value && std::is_convertible<decltype(r), F3>::value &&
                     std::is_convertible<decltype(ZS), F3>::value, "level-3 operand bound");
   decltype(mul(F3(), F3())) l3[4];
@@ -144,10 +144,10 @@ __device__ __forceinline__ Jac<G1CfgQ> jac_add(const Jac<G1CfgQ>& p, const Jac<G
   }
   const auto I = l3[0], RR = l3[1], ZZ = l3[2];
   const auto Zd = sub(ZZ, add(Z1Z1, Z2Z2));
-  using F4A = Fe<FqParams, 68>;
+  using F4A = Fe<FqParams, 80>;
   using F4B = Fe<FqParams, 49>;
-  static_assert(std::is_convertible<decltype(Zd), F4A>::value && std::is_convertible<decltype(H), F4B>::value,
-                "level-4 operand bound");
+  static_assert(std::is_convertible<decltype(Zd), F4A>::value && std::is_convertible<decltype(H), F4B>::value &&
+                    std::is_convertible<decltype(I), F4B>::value, "level-4 operand bound");
   decltype(mul(F4A(), F4B())) l4[4];
   {
     const F4A a[4] = {F4A(H), F4A(U1), F4A(Zd), F4A(Zd)};
