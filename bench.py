@@ -78,6 +78,23 @@ def java_baseline(bases, sc_host, n, result_bytes):
         return None
 
 
+def sclk_mhz():
+    """current shader clock of the card, best effort (sysfs; None when unreadable): with a ~10 % box-to-box spread a
+    kernel time means little without the clock it ran at"""
+    import glob
+    import re
+    for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+        try:
+            for line in open(f):
+                if "*" in line:
+                    m = re.search(r"(\d+)\s*Mhz", line, re.I)
+                    if m:
+                        return int(m.group(1))
+        except OSError:
+            pass
+    return None
+
+
 def base_seed(rank):
     return 2 + (rank << 32)
 
@@ -105,8 +122,11 @@ def main():
                          "BASELINE.json workload, whose every MSM starts from the JNI wire bytes")
     ap.add_argument("--in-flight", type=int, default=None,
                     help="MSMs in flight (default: 3 for --schedule streams, 2 for pipeline; 1 = strictly serial steps)")
-    ap.add_argument("--schedule", choices=["streams", "pipeline"], default="pipeline",
-                    help="pipeline (default): one head stream + one tail stream with the launch-order hint "
+    ap.add_argument("--tail-streams", type=int, default=2, help="pipeline3: streams the tails alternate on")
+    ap.add_argument("--schedule", choices=["streams", "pipeline", "pipeline3"], default=os.environ.get("OZK_BENCH_SCHEDULE", "pipeline3"),
+                    help="pipeline3 (default): sort of MSM k+1 | bucket accumulation of MSM k | tail of MSM k-1 on their own "
+                         "streams (device.VarMsmPipeline3); "
+                         "pipeline (rounds 1-2): one head stream + one tail stream with the launch-order hint "
                          "(device.VarMsmPipeline) — the level-1 kernel runs alone, so its HIP-event duration is the "
                          "kernel's own; streams: complete MSMs issued round-robin on independent streams, the way "
                          "concurrent prover threads drive the JNI — 5-8 %% more throughput at 3 in flight (590-620 "
@@ -114,7 +134,7 @@ def main():
                          "kernels stretch each other's duration, which would distort `roofline`")
     args = ap.parse_args()
     if args.in_flight is None:
-        args.in_flight = 3 if args.schedule == "streams" else 2
+        args.in_flight = 2 if args.schedule == "pipeline" else 3
 
     import torch
     import torch.distributed as dist
@@ -154,7 +174,10 @@ def main():
     bases = dev.gen_g1_bases(n, seed=base_seed(rank))
     sc_host = rand_scalars(n, scalar_seed(rank))
     scalars = torch.from_numpy(sc_host).cuda()
-    pipe = dev.VarMsmPipeline(n, 1, depth=max(1, args.in_flight))
+    if args.schedule == "pipeline3" and args.in_flight >= 2:
+        pipe = dev.VarMsmPipeline3(n, 1, depth=args.in_flight, tail_streams=args.tail_streams)
+    else:
+        pipe = dev.VarMsmPipeline(n, 1, depth=max(1, args.in_flight))
     msm_bases = pipe.prepare(bases) if args.prepared else bases
     wb, wn = ctypes.c_int32(), ctypes.c_int32()
     ozk.check(L.ozk_var_msm_plan(n, ctypes.byref(wb), ctypes.byref(wn)))
@@ -167,12 +190,18 @@ def main():
         # the step's result; for N > 1: RCCL all-gather of the 192-B partials + HIP point sum.
         # Issued on the pipeline's side stream (behind the tail it consumes), so the single-lane
         # point sum does not sit between two heads on the main stream.
-        if world == 1:
+        three = isinstance(pipe, dev.VarMsmPipeline3)
+        if world == 1 and not three:
             return pipe.result(ticket)
-        with torch.cuda.stream(pipe.side):
+        # three-stage schedule: the caller's stream is the SORT stream and must not wait for a tail, so the result
+        # is taken on the stream that ran this ticket's tail (the final barrier synchronises the device)
+        side = pipe.stream_of(ticket) if three else pipe.side
+        with torch.cuda.stream(side):
+            if world == 1:
+                return pipe.result(ticket)
             out = ozk_dist.distributed_var_msm(lambda: pipe.result(ticket), dev.points_sum, 1)
             done = torch.cuda.Event()
-            done.record(pipe.side)
+            done.record(side)
         finish.last_event = done
         return out
 
@@ -217,14 +246,32 @@ def main():
 
     res = run_steps(max(1, args.warmup))
     barrier()
-    ozk.check(L.ozk_prof_enable(1))
+    # level-1 kernel duration per launch, from the device clock stamped by the kernel's own waves (ozk_prof_enable(2)):
+    # HIP events on the dispatch perturb the three-stage schedule (4-13 % of its throughput), so they are taken in a
+    # second, untimed pass below and reported next to this figure
+    ozk.check(L.ozk_prof_enable(2))
     t0 = time.perf_counter()
     res = run_steps(args.steps)
     barrier()
     t1 = time.perf_counter()
-    avg_ms, launches = ctypes.c_double(), ctypes.c_int()
-    ozk.check(L.ozk_prof_dominant_kernel_ms(ctypes.byref(avg_ms), ctypes.byref(launches)))
+    kstats, launches = (ctypes.c_double * 4)(), ctypes.c_int()
+    ozk.check(L.ozk_prof_dominant_kernel_stats(kstats, ctypes.byref(launches)))
     ozk.check(L.ozk_prof_enable(0))
+    avg_ms = ctypes.c_double(kstats[0])
+    result_bytes = bytes(res.cpu().numpy())
+    ev_stats, ev_launches, ev_ms_per_step = None, 0, None
+    if not args.timed_only:
+        ozk.check(L.ozk_prof_enable(1))
+        e0 = time.perf_counter()
+        res_ev = run_steps(args.steps)
+        barrier()
+        e1 = time.perf_counter()
+        es, el = (ctypes.c_double * 4)(), ctypes.c_int()
+        ozk.check(L.ozk_prof_dominant_kernel_stats(es, ctypes.byref(el)))
+        ozk.check(L.ozk_prof_enable(0))
+        ev_stats, ev_launches, ev_ms_per_step = [float(x) for x in es], el.value, (e1 - e0) / args.steps * 1e3
+        if bytes(res_ev.cpu().numpy()) != result_bytes:
+            raise SystemExit("bench: the HIP-event pass returned a different point")
     # latency of ONE MSM with nothing else in flight (not part of `value`)
     lat = []
     for _ in range(0 if args.timed_only else 5):
@@ -261,7 +308,6 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    result_bytes = bytes(res.cpu().numpy())
 
     if rank == 0:
         value = world * n * args.steps / elapsed / 1e6
@@ -283,6 +329,17 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                     "kernel": "k_segreduce<G1Cfg,true> (level-1 bucket accumulation)",
                     "kernel_avg_ms": round(k_ms, 4), "launches_timed": launches.value,
+                    "kernel_ms": {"mean": round(kstats[0], 4), "median": round(kstats[1], 4), "min": round(kstats[2], 4),
+                                  "max": round(kstats[3], 4),
+                                  "source": "device clock stamped by the kernel's waves inside the timed region (first wave "
+                                            "start to last wave end)"},
+                    "kernel_ms_hip_events": None if ev_stats is None else {
+                        "mean": round(ev_stats[0], 4), "median": round(ev_stats[1], 4), "min": round(ev_stats[2], 4),
+                        "max": round(ev_stats[3], 4), "launches": ev_launches,
+                        "ms_per_step_of_that_pass": round(ev_ms_per_step, 4),
+                        "source": "HIP start/stop events on the dispatch, second pass of the same steps (an event-carrying "
+                                  "dispatch slows the three-stage schedule, hence not inside the timed region)"},
+                    "sclk_mhz": sclk_mhz(),
                     "algorithmic_bytes_per_launch": alg_bytes,
                     # the bound that actually holds: v_mad_u64_u32 issue.  10 Montgomery
                     # multiplications per XYZZ mixed addition x points x windows, against the 179 G mulmod/s

@@ -148,6 +148,13 @@ int ozk_var_msm_sort_dev(const void* d_bases, const void* d_scalars, int32_t n, 
 int ozk_var_msm_accum_dev(int32_t n, int32_t type, void* d_sorted, size_t sorted_bytes,
                           void* d_accum_ws, size_t accum_ws_bytes, void* d_tail, size_t tail_bytes,
                           void* stream);
+/* the same two stages over prepared bases (ozk_var_msm_prepare_dev): the sort skips the base conversion */
+int ozk_var_msm_sort_prepared_dev(const void* d_prepared, const void* d_scalars, int32_t n, int32_t type,
+                                  void* d_sorted, size_t sorted_bytes, void* d_sort_ws, size_t sort_ws_bytes,
+                                  void* stream);
+int ozk_var_msm_accum_prepared_dev(const void* d_prepared, int32_t n, int32_t type, void* d_sorted,
+                                   size_t sorted_bytes, void* d_accum_ws, size_t accum_ws_bytes, void* d_tail,
+                                   size_t tail_bytes, void* stream);
 size_t ozk_var_msm_head_workspace_bytes(int32_t n, int32_t type);
 size_t ozk_var_msm_tail_bytes(int32_t n, int32_t type);
 int ozk_var_msm_head_dev(const void* d_bases, const void* d_scalars, int32_t n, int32_t type,
@@ -161,12 +168,19 @@ int ozk_var_msm_tail_dev(int32_t n, int32_t type, void* d_tail, size_t tail_byte
  * reduce(GroupT::add) of VariableBaseMSM.java:777-783 after the RCCL all-gather. */
 int ozk_points_sum_dev(const void* d_points, int32_t k, int32_t type, void* d_out, void* stream);
 
-/* Measurement hooks (bench.py): when enabled, ozk_var_msm_dev brackets its dominant kernel
- * (the level-1 bucket accumulation, k_segreduce<.., true>) with HIP events on the launch
- * stream; ozk_prof_dominant_kernel_ms returns the mean duration over the launches since
- * ozk_prof_enable(1).  ozk_var_msm_plan reports the window size the library picks for n. */
+/* Measurement hooks (bench.py): timing of the dominant kernel (the level-1 bucket accumulation,
+ * k_segreduce<.., true>) per launch.  ozk_prof_enable(2): the kernel's own waves stamp the device's constant-rate
+ * clock (first wave start -> last wave end), which leaves the schedule untouched; ozk_prof_enable(1): HIP start /
+ * stop events on the dispatch (16 + k: on every (k+1)-th launch only) — exact too, but an event-carrying dispatch
+ * costs the three-stage schedule 4-13 % of its throughput, so bench.py uses it as a cross-check in a second pass;
+ * 0: off (the recorded launches stay readable).  ozk_prof_dominant_kernel_ms returns the mean duration over the
+ * launches since the last enable, _stats the distribution.  ozk_var_msm_plan reports the window size the library
+ * picks for n. */
 int ozk_prof_enable(int on);
 int ozk_prof_dominant_kernel_ms(double* avg_ms, int* launches);
+/* stats4 = {mean, median, min, max} in ms (the box-to-box spread of the pool is ~10 %, so a single mean cannot
+ * tell a 5 % gain from a slower box) */
+int ozk_prof_dominant_kernel_stats(double* stats4, int* launches);
 int ozk_var_msm_plan(int32_t n, int32_t* window_bits, int32_t* windows);
 /* 1 when the MSM of n pairs runs as 2n half-length pairs through the GLV endomorphism (the windows
  * reported above then cover 128 bits); 0 otherwise (n > 2^23 or OZK_MSM_GLV=0). */

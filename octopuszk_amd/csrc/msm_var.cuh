@@ -490,15 +490,31 @@ static __global__ void __launch_bounds__(SORT_BLOCK) k_sortbig_scatter(const u32
   }
 }
 
-// one block per coarse bin (w, h): finishes the sort inside the bin
-static __global__ void __launch_bounds__(SORT_BLOCK) k_sort2(const u32* __restrict__ coarse, const u32* __restrict__ P1,
+// one block per coarse bin (w, h): finishes the sort inside the bin.
+// Shaped to run BESIDE the bucket accumulation of the previous MSM (three-stage schedule): that kernel
+// leaves 128 VGPRs per SIMD and ~38 KiB of LDS per CU free, so this one is 512 threads (two waves per SIMD) of at most
+// 64 VGPRs and 38 KiB: the register tile is 17 entries per thread (round 2: 256 threads x 36 = 181 VGPRs, 42 KiB —
+// it could not be resident next to three accumulation blocks and the overlapped sort took 1.5 ms instead of 0.33).
+// The bin goes through the register tile + LDS staging array tile by tile (ONE tile for every bin of a uniform input
+// up to 2^20 pairs): per tile a local count, a local scan, a local rank into the staging array, then every bucket's
+// piece of the tile is appended to its run in the output — consecutive lanes write consecutive words.  Bins of
+// several tiles (n >= 2^21: 16384 and more entries per bin) need the bin-wide bucket offsets first: one extra
+// streaming count over the bin.  (The plain two-sweep form with scattered 4-byte writes took 0.59 ms at 2^21 and
+// 2.9 ms at 2^23.)  Loads are unpredicated (index clamped to the bin's last entry): 17 predicated loads cost 34
+// SGPRs of masks and a branch each.
+constexpr int SORT2_BLOCK = 512;
+constexpr int S2_PER = 17;
+constexpr u32 S2_TILE = S2_PER * SORT2_BLOCK;  // 8704: a coarse bin of 2^21 points (GLV at 2^20) holds 8192 +- 90
+static __global__ void __launch_bounds__(SORT2_BLOCK, 8) k_sort2(const u32* __restrict__ coarse, const u32* __restrict__ P1,
                                                       const u32* __restrict__ total, int c, int lo_bits, int NH,
                                                       u32 sign_bit, int nblk, int nbins, u32 big_thresh,
                                                       u32* __restrict__ hist, u32* __restrict__ sidx,
                                                       u32* __restrict__ sbid) {
-  __shared__ u32 cnt[256];
-  __shared__ u32 cur[256];
-  __shared__ u32 wsum[SORT_BLOCK / 64];
+  __shared__ u32 cnt[256];   // per-tile bucket counts (first: the bin-wide counts of a multi-tile bin)
+  __shared__ u32 cur[256];   // next output position of every bucket
+  __shared__ u32 lcur[256], gdelta[256];
+  __shared__ u32 wsum[4];
+  __shared__ u32 stage[S2_TILE];
   const int bin = blockIdx.x;
   const int NLO = 1 << lo_bits;
   const u32 lo_mask = (1u << lo_bits) - 1u;
@@ -507,127 +523,99 @@ static __global__ void __launch_bounds__(SORT_BLOCK) k_sort2(const u32* __restri
   const int w = bin / NH, h = bin - w * NH;
   const u32 bucket0 = ((u32)w << c) | ((u32)h << lo_bits);
   if (b1 - b0 > big_thresh) return;  // split over many blocks by the k_sortbig_* kernels
-  if (threadIdx.x < 256) cnt[threadIdx.x] = 0;
-  block_sync();
-  // Bins of at most S2_TILE entries (every bin of a uniform input: 2^c/2^8 ... n/256 entries) are
-  // held in registers between the counting and the scattering sweep: one pipelined read of the
-  // bin, no second read.  Larger bins (skewed digits) stream twice.
-  // register tile: 2^21 points (GLV at 2^20) put 8192 +- 90 entries into a coarse bin
-  constexpr int S2_PER = 36;
-  constexpr u32 S2_TILE = S2_PER * SORT_BLOCK;
-  __shared__ u32 stage[S2_TILE];
-  const bool small = (b1 - b0) <= S2_TILE;
-  u32 vreg[S2_PER];
-  if (small) {
-#pragma unroll
-    for (int k = 0; k < S2_PER; k++) {
-      const u32 e = b0 + k * SORT_BLOCK + threadIdx.x;
-      vreg[k] = (e < b1) ? coarse[e] : 0xffffffffu;
-    }
-#pragma unroll
-    for (int k = 0; k < S2_PER; k++) {
-      const u32 e = b0 + k * SORT_BLOCK + threadIdx.x;
-      lds_rank(cnt, vreg[k] & lo_mask, e < b1);
-    }
-  } else {
-    for (u32 e = b0 + threadIdx.x; e - threadIdx.x < b1; e += SORT_BLOCK) {  // uniform trip count
-      const bool live = e < b1;
-      const u32 v = live ? coarse[e] : 0u;
-      lds_rank(cnt, v & lo_mask, live);
-    }
-  }
-  block_sync();
-  // exclusive scan of the NLO (<= 256) counts
   const int t = threadIdx.x;
-  const u32 ct = (t < NLO) ? cnt[t] : 0u;
-  u32 incl = ct;
   const int lane = t & 63;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const u32 x = __shfl_up(incl, o);
-    if (lane >= o) incl += x;
+  if (b1 == b0) {  // empty bin: every bucket's count is still written (no memset of hist)
+    if (t < NLO) hist[bucket0 + t] = 0;
+    return;
   }
-  if (lane == 63) wsum[t >> 6] = incl;
-  block_sync();
-  u32 woff = 0;
-  for (int k = 0; k < (t >> 6); k++) woff += wsum[k];
-  const u32 excl = woff + incl - ct;
-  if (t < NLO) {
-    hist[bucket0 + t] = ct;
-    cur[t] = b0 + excl;
-  }
-  block_sync();
-  if (small) {
-#pragma unroll
-    for (int k = 0; k < S2_PER; k++) {
-      const u32 e = b0 + k * SORT_BLOCK + threadIdx.x;
-      const bool live = e < b1;
-      const u32 lo = vreg[k] & lo_mask;
-      const u32 pos = lds_rank(cur, lo, live);
-      if (live) stage[pos - b0] = vreg[k];
-    }
-    block_sync();
-    // sorted inside LDS; write out in order (coalesced)
-    for (u32 j = threadIdx.x; j < b1 - b0; j += SORT_BLOCK) {
-      const u32 v = stage[j];
-      sidx[b0 + j] = (v >> 8) | ((v & sign_bit) << 24);
-      sbid[b0 + j] = bucket0 + (v & lo_mask);
-    }
-  } else {
-    // Larger bins (n >= 2^21: 16384 and more entries per bin) go tile by tile through the same register
-    // tile + LDS staging: per tile a local count, a local scan, a local rank into the staging array,
-    // then every bucket's piece of the tile is appended to its run in the output — consecutive lanes
-    // write consecutive words.  (The plain two-sweep form with scattered 4-byte writes took 0.59 ms at
-    // 2^21 and 2.9 ms at 2^23.)
-    __shared__ u32 tcnt[256], lcur[256], gdelta[256];
-    for (u32 t0 = b0; t0 < b1; t0 += S2_TILE) {  // uniform trip count
-      const u32 t1 = (t0 + S2_TILE < b1) ? t0 + S2_TILE : b1;
-      tcnt[threadIdx.x] = 0;
-      block_sync();
-#pragma unroll
-      for (int k = 0; k < S2_PER; k++) {
-        const u32 e = t0 + k * SORT_BLOCK + threadIdx.x;
-        vreg[k] = (e < t1) ? coarse[e] : 0xffffffffu;
-      }
-#pragma unroll
-      for (int k = 0; k < S2_PER; k++) {
-        const u32 e = t0 + k * SORT_BLOCK + threadIdx.x;
-        lds_rank(tcnt, vreg[k] & lo_mask, e < t1);
-      }
-      block_sync();
-      const u32 tc = tcnt[t];
-      u32 ti = tc;
+  const u32 last = b1 - 1u;
+  const bool small = (b1 - b0) <= S2_TILE;
+  // exclusive scan of the 256 counters in cnt[] by the first four waves; returns this thread's count and offset
+  auto scan_cnt = [&](u32& ct, u32& excl) {
+    u32 incl = 0;
+    ct = 0;
+    if (t < 256) {
+      ct = cnt[t];
+      incl = ct;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
-        const u32 x = __shfl_up(ti, o);
-        if (lane >= o) ti += x;
+        const u32 x = __shfl_up(incl, o);
+        if (lane >= o) incl += x;
       }
-      if (lane == 63) wsum[t >> 6] = ti;
-      block_sync();
-      u32 two = 0;
-      for (int k = 0; k < (t >> 6); k++) two += wsum[k];
-      const u32 lstart = two + ti - tc;    // start of this bucket's piece inside the staged tile
-      lcur[t] = lstart;
-      gdelta[t] = cur[t] - lstart;         // output position = staged position + gdelta
-      cur[t] += tc;
-      block_sync();
-#pragma unroll
-      for (int k = 0; k < S2_PER; k++) {
-        const u32 e = t0 + k * SORT_BLOCK + threadIdx.x;
-        const bool live = e < t1;
-        const u32 r = lds_rank(lcur, vreg[k] & lo_mask, live);
-        if (live) stage[r] = vreg[k];
-      }
-      block_sync();
-      for (u32 j = threadIdx.x; j < t1 - t0; j += SORT_BLOCK) {
-        const u32 v = stage[j];
-        const u32 lo = v & lo_mask;
-        const u32 pos = j + gdelta[lo];
-        sidx[pos] = (v >> 8) | ((v & sign_bit) << 24);
-        sbid[pos] = bucket0 + lo;
-      }
-      block_sync();
+      if (lane == 63) wsum[t >> 6] = incl;
     }
+    block_sync();
+    u32 woff = 0;
+    if (t < 256)
+      for (int k = 0; k < (t >> 6); k++) woff += wsum[k];
+    excl = woff + incl - ct;
+  };
+  if (t < 256) cnt[t] = 0;
+  block_sync();
+  if (!small) {
+    for (u32 e = b0 + t; e - t < b1; e += SORT2_BLOCK) {  // uniform trip count
+      const bool live = e < b1;
+      const u32 v = coarse[live ? e : last];
+      lds_rank(cnt, v & lo_mask, live);
+    }
+    block_sync();
+    u32 ct, excl;
+    scan_cnt(ct, excl);
+    if (t < NLO) {
+      hist[bucket0 + t] = ct;
+      cur[t] = b0 + excl;
+    }
+    block_sync();
+    if (t < 256) cnt[t] = 0;
+    block_sync();
+  }
+  u32 vreg[S2_PER];
+  for (u32 t0 = b0; t0 < b1; t0 += S2_TILE) {  // uniform trip count
+    const u32 t1 = (t0 + S2_TILE < b1) ? t0 + S2_TILE : b1;
+#pragma unroll
+    for (int k = 0; k < S2_PER; k++) {
+      const u32 e = t0 + k * SORT2_BLOCK + t;
+      vreg[k] = coarse[e < last ? e : last];
+    }
+#pragma unroll
+    for (int k = 0; k < S2_PER; k++) {
+      const u32 e = t0 + k * SORT2_BLOCK + t;
+      lds_rank(cnt, vreg[k] & lo_mask, e < t1);
+    }
+    block_sync();
+    u32 tc, lstart;  // this bucket's count in the tile, start of its piece inside the staged tile
+    scan_cnt(tc, lstart);
+    if (t < 256) {
+      u32 cur_t;
+      if (small) {
+        cur_t = b0 + lstart;
+        if (t < NLO) hist[bucket0 + t] = tc;
+      } else {
+        cur_t = cur[t];
+        cur[t] = cur_t + tc;
+      }
+      lcur[t] = lstart;
+      gdelta[t] = cur_t - lstart;  // output position = staged position + gdelta
+      cnt[t] = 0;                  // (for the next tile; everybody has read its count)
+    }
+    block_sync();
+#pragma unroll
+    for (int k = 0; k < S2_PER; k++) {
+      const u32 e = t0 + k * SORT2_BLOCK + t;
+      const bool live = e < t1;
+      const u32 r = lds_rank(lcur, vreg[k] & lo_mask, live);
+      if (live) stage[r] = vreg[k];
+    }
+    block_sync();
+    for (u32 j = t; j < t1 - t0; j += SORT2_BLOCK) {
+      const u32 v = stage[j];
+      const u32 lo = v & lo_mask;
+      const u32 pos = j + gdelta[lo];
+      sidx[pos] = (v >> 8) | ((v & sign_bit) << 24);
+      sbid[pos] = bucket0 + lo;
+    }
+    block_sync();
   }
 }
 
@@ -1005,15 +993,25 @@ segreduce_lane(const int t, const u32* __restrict__ bid_in, const u32* __restric
   bid_out[2 * (size_t)t + 1] = tail_bid;
 }
 
+// `clk` (level 1 only; may be null): two device-clock words of this launch, zero before it.  Every wave leaves
+// max(~start) in clk[0] and max(end) in clk[1] (wall_clock64: the constant-rate counter, hipDeviceAttributeWallClockRate),
+// so the launch's duration is clk[1] - ~clk[0] without any help from the runtime: HIP events around (or on) the
+// dispatch cost the three-stage schedule 4-13 % of its throughput, see ozk_prof_enable.
 template <class CV, bool FIRST>
 __global__ void __launch_bounds__(256, (FIRST && CV::LDS_ACC) ? 2 : 1)
 k_segreduce(const u32* __restrict__ bid_in, const u32* __restrict__ idx_in, const u32* __restrict__ pts_in,
             const u32* __restrict__ d_count, int n_in_static, int L,
             u32* __restrict__ buckets, u32* __restrict__ bid_out, u32* __restrict__ pts_out,
-            int n_lanes) {
+            int n_lanes, unsigned long long* __restrict__ clk) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n_lanes) return;
-  segreduce_lane<CV, FIRST>(t, bid_in, idx_in, pts_in, d_count, n_in_static, L, buckets, bid_out, pts_out);
+  if constexpr (FIRST) {
+    if (clk != nullptr && (threadIdx.x & 63) == 0) atomicMax(&clk[0], ~(unsigned long long)wall_clock64());
+  }
+  if (t < n_lanes)
+    segreduce_lane<CV, FIRST>(t, bid_in, idx_in, pts_in, d_count, n_in_static, L, buckets, bid_out, pts_out);
+  if constexpr (FIRST) {
+    if (clk != nullptr && (threadIdx.x & 63) == 0) atomicMax(&clk[1], (unsigned long long)wall_clock64());
+  }
 }
 
 // The last generic levels (a few hundred lanes and fewer) in ONE single-block launch instead of one

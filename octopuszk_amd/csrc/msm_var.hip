@@ -4,6 +4,7 @@
 // the two JNI natives of algebra.msm.VariableBaseMSM (.cu:1614-1788).
 #include "msm_var_driver.cuh"
 
+#include <algorithm>
 #include <string>
 #include <thread>
 #include <vector>
@@ -194,11 +195,32 @@ int ozk_var_msm_accum_dev(int32_t n, int32_t type, void* d_sorted, size_t sorted
   return var_msm_accum<G2Cfg>(n, d_sorted, sorted_bytes, d_accum_ws, accum_ws_bytes, d_tail, tail_bytes,
                               (hipStream_t)stream);
 }
+int ozk_var_msm_sort_prepared_dev(const void* d_prepared, const void* d_scalars, int32_t n, int32_t type, void* d_sorted,
+                                  size_t sorted_bytes, void* d_sort_ws, size_t sort_ws_bytes, void* stream) {
+  if (!d_prepared || !d_scalars || !d_sorted || !d_sort_ws) return fail(OZK_E_INVALID, "null pointer argument");
+  if (n <= 0 || n > (1 << 24)) return fail(OZK_E_INVALID, "batch_size %d out of range [1, 2^24]", n);
+  if (type == OZK_G1)
+    return var_msm_sort<G1Cfg>(nullptr, d_scalars, n, d_sorted, sorted_bytes, d_sort_ws, sort_ws_bytes,
+                               (hipStream_t)stream, nullptr, d_prepared);
+  return var_msm_sort<G2Cfg>(nullptr, d_scalars, n, d_sorted, sorted_bytes, d_sort_ws, sort_ws_bytes,
+                             (hipStream_t)stream, nullptr, d_prepared);
+}
+int ozk_var_msm_accum_prepared_dev(const void* d_prepared, int32_t n, int32_t type, void* d_sorted, size_t sorted_bytes,
+                                   void* d_accum_ws, size_t accum_ws_bytes, void* d_tail, size_t tail_bytes,
+                                   void* stream) {
+  if (!d_prepared || !d_sorted || !d_accum_ws || !d_tail) return fail(OZK_E_INVALID, "null pointer argument");
+  if (n <= 0 || n > (1 << 24)) return fail(OZK_E_INVALID, "batch_size %d out of range [1, 2^24]", n);
+  if (type == OZK_G1)
+    return var_msm_accum<G1Cfg>(n, d_sorted, sorted_bytes, d_accum_ws, accum_ws_bytes, d_tail, tail_bytes,
+                                (hipStream_t)stream, d_prepared);
+  return var_msm_accum<G2Cfg>(n, d_sorted, sorted_bytes, d_accum_ws, accum_ws_bytes, d_tail, tail_bytes,
+                              (hipStream_t)stream, d_prepared);
+}
 int ozk_var_msm_tail_dev(int32_t n, int32_t type, void* d_tail, size_t tail_bytes, void* d_out, void* stream) {
   if (!d_tail || !d_out) return fail(OZK_E_INVALID, "null pointer argument");
   if (n <= 0 || n > (1 << 24)) return fail(OZK_E_INVALID, "batch_size %d out of range [1, 2^24]", n);
-  if (type == OZK_G1) return var_msm_tail<G1Cfg>(n, d_tail, tail_bytes, d_out, (hipStream_t)stream);
-  return var_msm_tail<G2Cfg>(n, d_tail, tail_bytes, d_out, (hipStream_t)stream);
+  if (type == OZK_G1) return var_msm_tail<G1Cfg>(n, d_tail, tail_bytes, d_out, (hipStream_t)stream, nullptr, TAIL_THROUGHPUT);
+  return var_msm_tail<G2Cfg>(n, d_tail, tail_bytes, d_out, (hipStream_t)stream, nullptr, TAIL_THROUGHPUT);
 }
 
 int ozk_var_msm_host(const uint8_t* bases, const uint8_t* scalars, int32_t n, int32_t type, int32_t task_id,
@@ -381,29 +403,87 @@ int ozk_gen_bases_dev(uint64_t seed, int32_t n, int32_t type, void* d_out_wire, 
 }
 
 int ozk_prof_enable(int on) {
-  if (on && !g_prof.created) {
-    for (int i = 0; i < ProfState::MAXP; i++) {
-      OZK_HIP(hipEventCreate(&g_prof.e0[i]));
-      OZK_HIP(hipEventCreate(&g_prof.e1[i]));
+  if (on == PROF_CLOCK) {
+    constexpr int CAP = 1 << 16;  // launches per enable
+    int dev = 0;
+    OZK_HIP(hipGetDevice(&dev));
+    if (g_prof.d_clk && g_prof.clk_device != dev) {
+      hipFree(g_prof.d_clk);
+      g_prof.d_clk = nullptr;
     }
+    if (!g_prof.d_clk) {
+      OZK_HIP(hipMalloc((void**)&g_prof.d_clk, (size_t)CAP * 2 * sizeof(unsigned long long)));
+      g_prof.clk_cap = CAP;
+      g_prof.clk_device = dev;
+    }
+    OZK_HIP(hipMemset(g_prof.d_clk, 0, (size_t)CAP * 2 * sizeof(unsigned long long)));
+    g_prof.mode = g_prof.src = PROF_CLOCK;
+    g_prof.count = 0;
+    return OZK_OK;
+  }
+  if (on && !g_prof.created) {
+    hipEvent_t a, b;
+    g_prof.count = 0;
+    if (!g_prof.slot(&a, &b)) return fail(OZK_E_NOMEM, "cannot create profiling events");
     g_prof.created = true;
   }
-  g_prof.on = on != 0;
-  g_prof.count = 0;
+  if (on) {
+    g_prof.mode = g_prof.src = PROF_EVENTS;
+    g_prof.every = on >= 16 ? on - 16 + 1 : 1;  // on = 16 + k: time every (k + 1)-th launch only
+    g_prof.seen = 0;
+    g_prof.count = 0;
+  } else {
+    g_prof.mode = PROF_OFF;  // (the recorded launches stay readable until the next enable)
+  }
+  return OZK_OK;
+}
+
+// stats[0..3] = mean, median, min, max duration (ms) of the level-1 launches recorded since the last ozk_prof_enable
+int ozk_prof_dominant_kernel_stats(double* stats4, int* launches) {
+  if (!stats4 || !launches) return fail(OZK_E_INVALID, "null pointer argument");
+  std::vector<double> d;
+  double tot = 0;
+  if (g_prof.d_clk && g_prof.src == PROF_CLOCK) {
+    int khz = 0;
+    OZK_HIP(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, g_prof.clk_device));
+    if (khz <= 0) return fail(OZK_E_INTERNAL, "device reports no wall clock rate");
+    OZK_HIP(hipDeviceSynchronize());
+    std::vector<unsigned long long> h((size_t)g_prof.count * 2);
+    if (g_prof.count)
+      OZK_HIP(hipMemcpy(h.data(), g_prof.d_clk, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int i = 0; i < g_prof.count; i++) {
+      const unsigned long long t0 = ~h[2 * i], t1 = h[2 * i + 1];
+      if (h[2 * i] == 0 || t1 < t0) continue;  // launch never ran
+      const double ms = (double)(t1 - t0) / (double)khz;
+      d.push_back(ms);
+      tot += ms;
+    }
+  } else {
+    for (int i = 0; i < g_prof.count; i++) {
+      float ms = 0;
+      OZK_HIP(hipEventSynchronize(g_prof.e1[i]));
+      OZK_HIP(hipEventElapsedTime(&ms, g_prof.e0[i], g_prof.e1[i]));
+      d.push_back(ms);
+      tot += ms;
+    }
+  }
+  *launches = (int)d.size();
+  stats4[0] = stats4[1] = stats4[2] = stats4[3] = 0.0;
+  if (d.empty()) return OZK_OK;
+  std::sort(d.begin(), d.end());
+  stats4[0] = tot / (double)d.size();
+  stats4[1] = d[d.size() / 2];
+  stats4[2] = d.front();
+  stats4[3] = d.back();
   return OZK_OK;
 }
 
 int ozk_prof_dominant_kernel_ms(double* avg_ms, int* launches) {
   if (!avg_ms || !launches) return fail(OZK_E_INVALID, "null pointer argument");
-  double tot = 0;
-  for (int i = 0; i < g_prof.count; i++) {
-    float ms = 0;
-    OZK_HIP(hipEventSynchronize(g_prof.e1[i]));
-    OZK_HIP(hipEventElapsedTime(&ms, g_prof.e0[i], g_prof.e1[i]));
-    tot += ms;
-  }
-  *launches = g_prof.count;
-  *avg_ms = g_prof.count ? tot / g_prof.count : 0.0;
+  double st[4];
+  const int rc = ozk_prof_dominant_kernel_stats(st, launches);
+  if (rc) return rc;
+  *avg_ms = st[0];
   return OZK_OK;
 }
 

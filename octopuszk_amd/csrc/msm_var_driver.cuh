@@ -2,6 +2,7 @@
 // prepared-bases paths), shared by the two translation units that instantiate them — msm_var.hip
 // (G1 + the C ABI) and msm_var_g2.hip (G2) — so that the two heavy instantiations compile in parallel.
 #pragma once
+#include <hip/hip_ext.h>
 #include <pthread.h>
 #include <stdlib.h>
 
@@ -16,15 +17,39 @@
 
 namespace ozk {
 
-// Optional per-launch timing of the dominant kernel (level-1 segmented reduce) with HIP
-// events recorded on the stream it is launched on; bench.py reads the average after its
-// timed region (roofline.achieved).
+// Optional per-launch timing of the dominant kernel (level-1 segmented reduce); bench.py reads the statistics after
+// its timed region (roofline.achieved).  Two sources:
+//   PROF_CLOCK  the kernel's own waves stamp the device's constant-rate clock (k_segreduce, `clk`): no runtime
+//               involvement, so the schedule being measured is the schedule that runs;
+//   PROF_EVENTS HIP events on the dispatch (hipExtLaunchKernelGGL start / stop events).  Exact too, but an event-
+//               carrying dispatch costs the three-stage schedule throughput (684 -> 597 Mscalar-mul/s with every
+//               launch timed, 660 with one in ten; separate hipEventRecord calls around the launch: 589), so
+//               bench.py uses it in a second pass as the cross-check, not inside the timed region.
+enum { PROF_OFF = 0, PROF_EVENTS = 1, PROF_CLOCK = 2 };
 struct ProfState {
-  bool on = false;
+  int mode = PROF_OFF;
+  int src = PROF_EVENTS;    // where the launches recorded since the last enable were timed
+  int every = 1, seen = 0;  // PROF_EVENTS: time one launch in `every`
   int count = 0;
-  static constexpr int MAXP = 512;
-  hipEvent_t e0[MAXP], e1[MAXP];
+  std::vector<hipEvent_t> e0, e1;  // grown in blocks of 512 as launches are recorded (no cap)
   bool created = false;
+  unsigned long long* d_clk = nullptr;  // PROF_CLOCK: 2 words per launch, zeroed by ozk_prof_enable
+  int clk_cap = 0, clk_device = -1;
+  // event pair for launch number `count`, or false when the pool cannot grow
+  bool slot(hipEvent_t* a, hipEvent_t* b) {
+    if ((size_t)count >= e0.size()) {
+      const size_t want = e0.size() + 512;
+      while (e0.size() < want) {
+        hipEvent_t x = nullptr, y = nullptr;
+        if (hipEventCreate(&x) != hipSuccess || hipEventCreate(&y) != hipSuccess) return false;
+        e0.push_back(x);
+        e1.push_back(y);
+      }
+    }
+    *a = e0[count];
+    *b = e1[count];
+    return true;
+  }
 };
 inline ProfState g_prof;
 
@@ -214,14 +239,34 @@ size_t tail_layout(const MsmPlan& p, MsmLayout& L, void* tail, size_t tail_bytes
 //     fused S=4, opening the tail phase, no issue priority      461-465 / 3.48-3.64
 //     fused S=16 / unfused S=8 in the tail, with or without priority: 372-420 (their 512-1024 waves
 //     sit on the same SIMDs as the next MSM's bucket accumulation and stretch it 1.35 -> 1.5-1.9 ms)
-static bool wsum0_in_tail() { return env_int("OZK_MSM_WSUM0_IN_TAIL", 1) != 0; }
-static bool wsum_fused() { return env_int("OZK_MSM_WSUM_FUSED", 1) != 0; }
+// Two shapes of the window sums, chosen per call (OZK_MSM_TAIL_MODE=0/1 forces one):
+//   LATENCY (a lone MSM: ozk_var_msm_dev and the host-buffer entries): fused first level + wave-cooperative levels —
+//     the fewest dependent additions (8 + 13, then 13 per 64x), most of them on mostly idle lanes;
+//   THROUGHPUT (the staged entry points, whose callers keep several MSMs in flight): S buckets per lane serially
+//     (2 additions per bucket), then serial levels of S elements per lane (3 additions per element) down to 64
+//     elements per window, then one wave level — 3.0 additions per bucket instead of 5.25.  With the three-stage
+//     schedule the chip is bound by the SUM of everybody's vector-ALU work (the accumulation kernel stretches by
+//     whatever runs beside it), so the cheaper form wins although it is 4 launches and ~40 dependent additions
+//     longer: 607 -> 664 Mscalar-mul/s at 2^20 (profiles/r03_schedule_experiments.txt).
+enum { TAIL_LATENCY = 0, TAIL_THROUGHPUT = 1 };
+struct TailShape {
+  bool fused;
+  int serial_above;
+};
+static TailShape tail_shape(int mode) {
+  const int forced = env_int("OZK_MSM_TAIL_MODE", -1);
+  if (forced == 0 || forced == 1) mode = forced;
+  TailShape t;
+  t.fused = env_int("OZK_MSM_WSUM_FUSED", mode == TAIL_THROUGHPUT ? 0 : 1) != 0;
+  t.serial_above = env_int("OZK_MSM_TAIL_SERIAL_ABOVE", mode == TAIL_THROUGHPUT ? 64 : (1 << 30));
+  return t;
+}
 // elements per window the first level leaves, and the g (log2 of buckets per element) they carry
-static void first_level_shape(const MsmPlan& p, int* m_out, int* g_out) {
+static void first_level_shape(const MsmPlan& p, bool fused, int* m_out, int* g_out) {
   const int m_in = 1 << p.cb;
   const int nseg = (m_in + p.S - 1) / p.S;
   const int sg = ilog2((uint32_t)p.S);
-  if (wsum_fused()) {
+  if (fused) {
     *m_out = (nseg + 63) / 64;
     *g_out = sg + 6;
   } else {
@@ -229,14 +274,17 @@ static void first_level_shape(const MsmPlan& p, int* m_out, int* g_out) {
     *g_out = sg;
   }
 }
+// First window-sum level, always the first kernel of the TAIL (it reads the bucket records of the tail region).
+// Fused form: a lane sums S = 4 buckets, its wave combines the 64 lane results in registers -> W * 2^cb / 256
+// elements.
 template <class CV>
-void launch_wsum0(const MsmPlan& p, const MsmLayout& L, hipStream_t st, int prio) {
+void launch_wsum0(const MsmPlan& p, const MsmLayout& L, hipStream_t st, int prio, bool fused) {
   const int TB = 256;
   const int m_in = 1 << p.cb;
   int m_out, g;
-  first_level_shape(p, &m_out, &g);
+  first_level_shape(p, fused, &m_out, &g);
   const int tot = m_out * p.W;
-  if (wsum_fused())
+  if (fused)
     hipLaunchKernelGGL((k_wsum_fused<CV>), dim3(tot), dim3(64), 0, st, L.buckets, L.hist_t, m_in, p.S,
                        ilog2((uint32_t)p.S), L.wA[0], L.wR[0], m_out, p.W, prio);
   else
@@ -296,7 +344,7 @@ int var_msm_sort(const void* d_bases, const void* d_scalars, int n, void* sorted
   if (L.cap / ((size_t)big_thresh + 1) > (size_t)SORTBIG_MAXBINS)
     return fail(OZK_E_INVALID, "window plan c=%d (W=%d) at n=%d can produce more than %d oversized sort bins",
                 p.c, p.W, p.n_in, SORTBIG_MAXBINS);
-  hipLaunchKernelGGL(k_sort2, dim3(nbins), dim3(SORT_BLOCK), 0, st, L.coarse, L.P1, L.total, p.cb, L.lo_bits, L.NH,
+  hipLaunchKernelGGL(k_sort2, dim3(nbins), dim3(SORT2_BLOCK), 0, st, L.coarse, L.P1, L.total, p.cb, L.lo_bits, L.NH,
                      sign_bit, L.nblk, nbins, big_thresh, L.hist, L.sidx, L.sbid);
   // Ordering hint for pipelined MSMs (see ozk_var_msm_tail_ordered_dev): everything up to here may
   // overlap the previous MSM's window-sum levels; the bucket accumulation that follows fills every
@@ -331,23 +379,32 @@ int var_msm_accum(int n, void* sorted, size_t sorted_bytes, void* accum_ws, size
   const int TB = 256;
   // level 1 over the sorted entries
   size_t lanes = (L.cap + p.L1 - 1) / p.L1;
-  const bool prof = g_prof.on && g_prof.created && g_prof.count < ProfState::MAXP;
-  if (prof) hipEventRecord(g_prof.e0[g_prof.count], st);
+  hipEvent_t prof_e0 = nullptr, prof_e1 = nullptr;
+  // the events ride on the kernel's own dispatch packet (hipExtLaunchKernelGGL start / stop events): separate
+  // hipEventRecord calls put two barrier packets around the launch, which cost the three-stage schedule 8 % of its
+  // throughput (637 -> 589 Mscalar-mul/s, profiles/r03_schedule_experiments.txt)
+  const bool prof = g_prof.mode == PROF_EVENTS && g_prof.created && (g_prof.seen++ % g_prof.every) == 0 &&
+                    g_prof.slot(&prof_e0, &prof_e1);
+  unsigned long long* clk = nullptr;
+  if (g_prof.mode == PROF_CLOCK && g_prof.d_clk && g_prof.count < g_prof.clk_cap) clk = g_prof.d_clk + 2 * (size_t)g_prof.count++;
   size_t acc_lds = CV::LDS_ACC ? (size_t)RunAccLds<CV>::LDS_WORDS * TB * sizeof(u32) : 0;  // 72 KiB for G2
   // G1: the kernel needs no LDS, but 4 blocks of 4 x 128 VGPRs fill a CU's register files completely, and a
   // kernel of another stream (a concurrent MSM's tail) dispatched later finds no wave slot until a block
-  // retires (~0.7 ms).  Asking for 48 KiB of dynamic LDS caps it at 3 blocks per CU — one wave slot per
-  // SIMD stays free.  Measured: the kernel itself is as fast with 3 waves per SIMD as with 4 (1.404 vs
-  // 1.409 ms); two free-running MSM streams 416 -> 459 Mscalar-mul/s; the pipelined bench without the
-  // launch-order hint 417 -> 476 (with it: unchanged, 480).
-  if (!CV::LDS_ACC) acc_lds = (size_t)env_int("OZK_L1_LDS", 49152);
+  // retires (~0.7 ms).  Asking for just over a quarter of the CU's 160 KiB of LDS caps it at 3 blocks per CU —
+  // one wave slot and 128 VGPRs per SIMD stay free.  Measured: the kernel itself is as fast with 3 waves per
+  // SIMD as with 4 (1.404 vs 1.409 ms); two free-running MSM streams 416 -> 459 Mscalar-mul/s; the pipelined
+  // bench without the launch-order hint 417 -> 476 (with it: unchanged, 480).
+  // 40.25 KiB, not the 48 KiB of rounds 1-2: three blocks then leave 39.25 KiB to whatever runs beside them, which
+  // is what the next MSM's sort kernels (k_sort1_scatter 34 KiB, k_sort2 38 KiB) need to be resident at all.
+  if (!CV::LDS_ACC) acc_lds = (size_t)env_int("OZK_L1_LDS", 41216);
   if (acc_lds > 65536)
     OZK_HIP(hipFuncSetAttribute((const void*)(k_segreduce<CV, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)acc_lds));
-  hipLaunchKernelGGL((k_segreduce<CV, true>), dim3((unsigned)((lanes + TB - 1) / TB)), dim3(TB), acc_lds, st,
-                     L.sbid, L.sidx, L.aff, L.total, 0, p.L1, L.buckets, L.slot_bid[0], L.slot_pts[0],
-                     (int)lanes);
-  if (prof) hipEventRecord(g_prof.e1[g_prof.count++], st);
+  hipExtLaunchKernelGGL((k_segreduce<CV, true>), dim3((unsigned)((lanes + TB - 1) / TB)), dim3(TB), (uint32_t)acc_lds, st,
+                        prof ? prof_e0 : (hipEvent_t) nullptr, prof ? prof_e1 : (hipEvent_t) nullptr, 0u,
+                        (const u32*)L.sbid, (const u32*)L.sidx, (const u32*)L.aff, (const u32*)L.total, 0, p.L1,
+                        L.buckets, L.slot_bid[0], L.slot_pts[0], (int)lanes, clk);
+  if (prof) g_prof.count++;
   // run merge: completes every bucket cut into at most RUN_MAX pieces; counts the surviving slots
   size_t n_in = 2 * lanes;
   hipLaunchKernelGGL((k_runmerge<CT>), dim3((unsigned)((lanes + TB - 1) / TB)), dim3(TB), 0, st, L.slot_bid[0],
@@ -366,7 +423,8 @@ int var_msm_accum(int n, void* sorted, size_t sorted_bytes, void* accum_ws, size
     }
     hipLaunchKernelGGL((k_segreduce<CT, false>), dim3((unsigned)((lanes + TB - 1) / TB)), dim3(TB), 0, st,
                        first_generic ? L.slot_bid2 : L.slot_bid[cur], (const u32*)nullptr, L.slot_pts[cur],
-                       L.total + 1, (int)n_in, p.LK, L.buckets, L.slot_bid[cur ^ 1], L.slot_pts[cur ^ 1], (int)lanes);
+                       L.total + 1, (int)n_in, p.LK, L.buckets, L.slot_bid[cur ^ 1], L.slot_pts[cur ^ 1], (int)lanes,
+                       (unsigned long long*)nullptr);
     first_generic = false;
     if (lanes == 1) break;
     n_in = 2 * lanes;
@@ -374,7 +432,6 @@ int var_msm_accum(int n, void* sorted, size_t sorted_bytes, void* accum_ws, size
   }
   // the tail needs the bucket counts after the next head has reused the sorted set
   OZK_HIP(hipMemcpyAsync(L.hist_t, L.hist, L.NB * sizeof(u32), hipMemcpyDeviceToDevice, st));
-  if (!wsum0_in_tail()) launch_wsum0<CV>(p, L, st, 0);
   OZK_HIP(hipGetLastError());
   return OZK_OK;
 }
@@ -398,23 +455,22 @@ int var_msm_head(const void* d_bases, const void* d_scalars, int n, void* ws, si
 // windows, affine normalisation).  Reads only the tail buffers; writes the wire-out result.
 template <class CV>
 int var_msm_tail(int n, void* tail, size_t tail_bytes, void* d_out, hipStream_t st,
-                        hipEvent_t order_ev = nullptr) {
+                        hipEvent_t order_ev = nullptr, int mode = TAIL_LATENCY) {
   using CT = CV;
   const MsmPlan p = make_plan(n);
   MsmLayout L;
   L.m1 = (((size_t)1 << p.cb) + p.S - 1) / p.S;
   const size_t tneed = tail_layout<CV>(p, L, tail, tail_bytes);
   if (tneed > tail_bytes) return fail(OZK_E_INVALID, "tail buffer too small: need %zu bytes, got %zu", tneed, tail_bytes);
-  if (wsum0_in_tail()) launch_wsum0<CV>(p, L, st, env_int("OZK_MSM_WSUM0_PRIO", 0));
+  const TailShape shape = tail_shape(mode);
+  launch_wsum0<CV>(p, L, st, env_int("OZK_MSM_WSUM0_PRIO", 0), shape.fused);
   int m_in, g, k = 0;
-  first_level_shape(p, &m_in, &g);
+  first_level_shape(p, shape.fused, &m_in, &g);
   const int TB = 256;
   const int sg = ilog2((uint32_t)p.S);
-  // Optional serial S-per-lane levels first (3 additions per element instead of the wave form's
-  // 13, but 24 dependent additions deep).  Measured at 2^20: 0.17 ms less single-MSM latency, but
-  // 13 % LESS throughput with two MSMs in flight (its 256 long-running waves sit beside the next
-  // MSM's bucket accumulation), so the default is wave-cooperative levels only.
-  const int serial_above = env_int("OZK_MSM_TAIL_SERIAL_ABOVE", 1 << 30);
+  // Serial S-per-lane levels first in THROUGHPUT mode (3 additions per element instead of the wave form's 13, but
+  // 12 dependent additions deep per level); none in LATENCY mode (tail_shape above).
+  const int serial_above = shape.serial_above < 1 ? 1 : shape.serial_above;
   while (m_in > serial_above) {
     const int m_out = (m_in + p.S - 1) / p.S;
     const int tot = m_out * p.W;
@@ -731,7 +787,7 @@ int bases_msm(BasesHandle* h, const uint8_t* scalars, uint8_t* out) {
                                                      const void*);                                                   \
   PREFIX template int ozk::var_msm_head<ozk::G2Cfg>(const void*, const void*, int, void*, size_t, void*, size_t,     \
                                                     hipStream_t, hipEvent_t, const void*);                          \
-  PREFIX template int ozk::var_msm_tail<ozk::G2Cfg>(int, void*, size_t, void*, hipStream_t, hipEvent_t);             \
+  PREFIX template int ozk::var_msm_tail<ozk::G2Cfg>(int, void*, size_t, void*, hipStream_t, hipEvent_t, int);        \
   PREFIX template int ozk::var_msm_dev<ozk::G2Cfg>(const void*, const void*, int, void*, void*, size_t, hipStream_t,  \
                                                    const void*);                                                     \
   PREFIX template int ozk::var_msm_host<ozk::G2Cfg>(const uint8_t*, const uint8_t*, int, int, uint8_t*);             \

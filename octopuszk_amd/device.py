@@ -1,6 +1,7 @@
 """Device-resident entry points on torch CUDA(HIP) tensors: torch is plumbing only (HBM
 buffers, streams, torch.distributed); all arithmetic is in libozk_hip.so."""
 import ctypes
+import sys
 
 import torch
 
@@ -85,7 +86,7 @@ class VarMsmPipeline:
 
     def __del__(self):
         # never call into HIP while the interpreter (and possibly the HIP runtime) is being torn down
-        import sys
+        # (`sys` is a module-level import: an import statement here fails during interpreter shutdown)
         if sys is None or sys.is_finalizing():
             return
         try:
@@ -124,6 +125,94 @@ class VarMsmPipeline:
     def result(self, ticket):
         """Output tensor of `ticket` (valid until `depth` more submissions); the current stream
         waits for its tail."""
+        assert self.count - ticket <= self.depth, "result buffer already reused"
+        slot = ticket % self.depth
+        torch.cuda.current_stream().wait_event(self.tail_done[slot])
+        return self.outs[slot]
+
+
+class VarMsmPipeline3:
+    """Three-stage schedule of consecutive device-resident MSMs: SORT of MSM k+1 (base conversion, digits, counting
+    sort: HBM / LDS-bound) on the caller's stream | ACCUMULATE of MSM k (bucket accumulation, run merge: vector-ALU
+    bound) on a second stream | TAIL of MSM k-1 (window sums, Horner, normalisation: latency-bound) on one or two more.
+    The sort writes a double-buffered "sorted set"; each stage has private scratch (include/ozk.h,
+    ozk_var_msm_sort_dev / _accum_dev / _tail_dev).  The sort kernels are sized to be resident beside three
+    accumulation blocks per CU (csrc/msm_var.cuh, k_sort2), which is what lets the multiplier run back to back.
+    Same interface as VarMsmPipeline (submit -> ticket, result(ticket))."""
+
+    def __init__(self, n, type_=1, depth=3, tail_streams=2, device="cuda"):
+        L = _lib.load()
+        ts = max(1, tail_streams)
+        # a result slot is always served by the same tail stream (slot = k mod depth, stream = k mod ts), so whatever a
+        # caller enqueues on stream_of(ticket) after result(ticket) is ordered before the slot's next tail
+        self.n, self.type, self.depth = n, type_, (max(2, depth) + ts - 1) // ts * ts
+        sb, swb, awb = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+        _lib.check(L.ozk_var_msm_stage_bytes(n, type_, ctypes.byref(sb), ctypes.byref(swb), ctypes.byref(awb)))
+        self.sorted_bytes, self.sort_ws_bytes, self.accum_ws_bytes = sb.value, swb.value, awb.value
+        self.tail_bytes = int(L.ozk_var_msm_tail_bytes(n, type_))
+        buf = lambda b: torch.empty(b, dtype=torch.uint8, device=device)
+        self.sorted = [buf(self.sorted_bytes) for _ in range(2)]
+        self.sort_ws, self.accum_ws = buf(self.sort_ws_bytes), buf(self.accum_ws_bytes)
+        self.tails = [buf(self.tail_bytes) for _ in range(self.depth)]
+        self.outs = [torch.zeros(192 if type_ == 1 else 384, dtype=torch.uint8, device=device) for _ in range(self.depth)]
+        self.acc = torch.cuda.Stream(device=device)
+        self.tail_st = [torch.cuda.Stream(device=device) for _ in range(ts)]
+        self.side = self.tail_st[0]
+        ev = lambda k: [torch.cuda.Event() for _ in range(k)]
+        self.sort_done, self.accum_done = ev(2), ev(2)
+        self.tail_done = ev(self.depth)
+        self.count = 0
+        self._inputs = None
+
+    def close(self):
+        pass
+
+    def prepare(self, d_bases):
+        L = _lib.load()
+        nbytes = int(L.ozk_var_msm_prepared_bytes(self.n, self.type))
+        out = torch.empty(nbytes, dtype=torch.uint8, device=d_bases.device)
+        _lib.check(L.ozk_var_msm_prepare_dev(_ptr(d_bases), self.n, self.type, _ptr(out), nbytes, _stream()))
+        return out
+
+    def submit(self, d_bases, d_scalars, prepared=False):
+        L = _lib.load()
+        k = self.count
+        s, slot = k % 2, k % self.depth
+        main = torch.cuda.current_stream()
+        self._inputs = (d_bases, d_scalars)
+        if k >= 2:
+            main.wait_event(self.accum_done[s])        # sorted set s is free again
+        sort = L.ozk_var_msm_sort_prepared_dev if prepared else L.ozk_var_msm_sort_dev
+        _lib.check(sort(_ptr(d_bases), _ptr(d_scalars), self.n, self.type, _ptr(self.sorted[s]), self.sorted_bytes,
+                        _ptr(self.sort_ws), self.sort_ws_bytes, int(main.cuda_stream)))
+        self.sort_done[s].record(main)
+        self.acc.wait_event(self.sort_done[s])
+        if k >= self.depth:
+            self.acc.wait_event(self.tail_done[slot])  # the tail that last used this slot's buffers
+        if prepared:
+            _lib.check(L.ozk_var_msm_accum_prepared_dev(_ptr(d_bases), self.n, self.type, _ptr(self.sorted[s]),
+                                                        self.sorted_bytes, _ptr(self.accum_ws), self.accum_ws_bytes,
+                                                        _ptr(self.tails[slot]), self.tail_bytes,
+                                                        int(self.acc.cuda_stream)))
+        else:
+            _lib.check(L.ozk_var_msm_accum_dev(self.n, self.type, _ptr(self.sorted[s]), self.sorted_bytes,
+                                               _ptr(self.accum_ws), self.accum_ws_bytes, _ptr(self.tails[slot]),
+                                               self.tail_bytes, int(self.acc.cuda_stream)))
+        self.accum_done[s].record(self.acc)
+        T = self.tail_st[k % len(self.tail_st)]
+        T.wait_event(self.accum_done[s])
+        _lib.check(L.ozk_var_msm_tail_dev(self.n, self.type, _ptr(self.tails[slot]), self.tail_bytes,
+                                          _ptr(self.outs[slot]), int(T.cuda_stream)))
+        self.tail_done[slot].record(T)
+        self.count += 1
+        return k
+
+    def stream_of(self, ticket):
+        """the stream ticket's tail ran on: consumers of result(ticket) that must not stall the caller's (sort)
+        stream enqueue there"""
+        return self.tail_st[ticket % len(self.tail_st)]
+
+    def result(self, ticket):
         assert self.count - ticket <= self.depth, "result buffer already reused"
         slot = ticket % self.depth
         torch.cuda.current_stream().wait_event(self.tail_done[slot])

@@ -25,12 +25,15 @@ _SIGS = {
     "ozk_var_msm_dev": (ctypes.c_int, [vp, vp, i32, i32, vp, vp, sz, vp]),
     "ozk_prof_enable": (ctypes.c_int, [ctypes.c_int]),
     "ozk_prof_dominant_kernel_ms": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
+    "ozk_prof_dominant_kernel_stats": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
     "ozk_var_msm_plan": (ctypes.c_int, [i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]),
     "ozk_var_msm_glv": (ctypes.c_int, [i32]),
     "ozk_gen_bases_dev": (ctypes.c_int, [ctypes.c_uint64, i32, i32, vp, vp]),
     "ozk_var_msm_stage_bytes": (ctypes.c_int, [i32, i32, ctypes.POINTER(sz), ctypes.POINTER(sz), ctypes.POINTER(sz)]),
     "ozk_var_msm_sort_dev": (ctypes.c_int, [vp, vp, i32, i32, vp, sz, vp, sz, vp]),
     "ozk_var_msm_accum_dev": (ctypes.c_int, [i32, i32, vp, sz, vp, sz, vp, sz, vp]),
+    "ozk_var_msm_sort_prepared_dev": (ctypes.c_int, [vp, vp, i32, i32, vp, sz, vp, sz, vp]),
+    "ozk_var_msm_accum_prepared_dev": (ctypes.c_int, [vp, i32, i32, vp, sz, vp, sz, vp, sz, vp]),
     "ozk_var_msm_head_workspace_bytes": (sz, [i32, i32]),
     "ozk_var_msm_tail_bytes": (sz, [i32, i32]),
     "ozk_var_msm_head_dev": (ctypes.c_int, [vp, vp, i32, i32, vp, sz, vp, sz, vp]),

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Throughput of consecutive 2^logn G1 MSMs under one schedule, without bench.py's extras.
+usage: sched_probe.py [--sched p3|p2] [--reps N] [--depth D] [--tail-streams T] [--prof] [--logn L] [--prepared]
+                      [--own-sort-stream]"""
+import argparse, ctypes, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from octopuszk_amd import device as dev, lib as ozk
+ap = argparse.ArgumentParser()
+ap.add_argument("--sched", default="p3")
+ap.add_argument("--reps", type=int, default=100)
+ap.add_argument("--depth", type=int, default=3)
+ap.add_argument("--tail-streams", type=int, default=2)
+ap.add_argument("--logn", type=int, default=20)
+ap.add_argument("--prof", type=int, default=0)
+ap.add_argument("--prepared", action="store_true")
+ap.add_argument("--own-sort-stream", action="store_true")
+a = ap.parse_args()
+L = ozk.load()
+n = 1 << a.logn
+bases = dev.gen_g1_bases(n, seed=2)
+sc = np.random.default_rng(10).integers(0, 256, size=(n, 32), dtype=np.uint8); sc[:, 31] &= 0x1F
+d_sc = torch.from_numpy(sc.reshape(-1)).cuda()
+pipe = dev.VarMsmPipeline3(n, 1, depth=a.depth, tail_streams=a.tail_streams) if a.sched == "p3" else dev.VarMsmPipeline(n, 1, depth=2)
+b = pipe.prepare(bases) if a.prepared else bases
+st = torch.cuda.Stream() if a.own_sort_stream else torch.cuda.current_stream()
+with torch.cuda.stream(st):
+    for _ in range(6): t = pipe.submit(b, d_sc, prepared=a.prepared)
+    torch.cuda.synchronize()
+    if a.prof: ozk.check(L.ozk_prof_enable(a.prof))
+    t0 = time.perf_counter()
+    for _ in range(a.reps): t = pipe.submit(b, d_sc, prepared=a.prepared)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+msg = "%s depth=%d ts=%d prof=%d: %.1f Mscalar-mul/s (%.3f ms per MSM)" % (a.sched, a.depth, a.tail_streams, a.prof, a.reps * n / dt / 1e6, dt / a.reps * 1e3)
+if a.prof:
+    s4 = (ctypes.c_double * 4)(); k = ctypes.c_int()
+    ozk.check(L.ozk_prof_dominant_kernel_stats(s4, ctypes.byref(k)))
+    msg += "  level-1 ms mean/med/min/max = %.3f/%.3f/%.3f/%.3f (%d)" % (s4[0], s4[1], s4[2], s4[3], k.value)
+print(msg, flush=True)
