@@ -181,6 +181,9 @@ int ozk_prof_dominant_kernel_ms(double* avg_ms, int* launches);
 /* stats4 = {mean, median, min, max} in ms (the box-to-box spread of the pool is ~10 %, so a single mean cannot
  * tell a 5 % gain from a slower box) */
 int ozk_prof_dominant_kernel_stats(double* stats4, int* launches);
+/* ticks per millisecond of the device clock, calibrated against the host's steady clock by the first
+ * ozk_prof_enable(2) (MI355X: 100 011.8 kHz for a nominal 100 MHz); 0 before that */
+double ozk_prof_clock_khz(void);
 int ozk_var_msm_plan(int32_t n, int32_t* window_bits, int32_t* windows);
 /* 1 when the MSM of n pairs runs as 2n half-length pairs through the GLV endomorphism (the windows
  * reported above then cover 128 bits); 0 otherwise (n > 2^23 or OZK_MSM_GLV=0). */

@@ -231,6 +231,49 @@ OZK_HD Xyzz<CV> xyzz_madd(const Xyzz<CV>& p, const Aff<typename CV::EA>& q) {
   return out;
 }
 
+// The same madd-2008-s with the point SUBTRACTED when `negate` is set, carries left out wherever the consumer is a
+// multiplication (fp29.cuh FeL), base field only: three carry passes (P, R: they are squared; X3: it is stored)
+// instead of seven, and the negated y enters its one product as K p - y without reduction or carry.  The level-1
+// loop of the bucket accumulation is this function; loop-carried bounds CV::LX / LY (the fixed point of THIS
+// schedule: X3 collects 2 p + 4 p of bias instead of 4 p).
+template <class CV>
+OZK_HD Xyzz<CV> xyzz_madd_lazy(const Xyzz<CV>& p, const Aff<typename CV::EA>& q, bool negate) {
+  if (is_inf(q)) return p;
+  const auto yq = select_el(negate, neg_nc(q.y), q.y);  // +-y, loose
+  if (is_inf(p)) {
+    Aff<typename CV::EA> qs = q;
+    qs.y = typename CV::EA(reduce_to<17>(normalise(yq)));
+    return xyzz_from_affine<CV>(qs);
+  }
+  const auto U2 = mul(q.x, p.ZZ);
+  const auto S2 = mul(yq, p.ZZZ);
+  const auto P = sub(U2, p.X);
+  const auto R = sub(S2, p.Y);
+  // P == 0 is tested on P^2 (< 2p: two candidates to compare with, not the ten of P < 9.1 p)
+  const auto PP = sqr(P);
+  if (is_zero(PP)) {
+    if (is_zero(R)) {  // P == +-Q
+      Aff<typename CV::EA> qs = q;
+      qs.y = typename CV::EA(reduce_to<17>(normalise(yq)));
+      return xyzz_dbl_affine<CV>(qs);
+    }
+    Xyzz<CV> z = p;  // P == -(+-Q): infinity
+    z.ZZ = typename CV::XZZ(el_zero(q.x));
+    z.ZZZ = typename CV::XZZZ(el_zero(q.x));
+    return z;
+  }
+  const auto PPP = mul(P, PP);
+  const auto Q = mul(p.X, PP);
+  const auto X3 = sub_sub2(sqr(R), PPP, Q);
+  const auto Y3 = mul2(sub_nc(Q, X3), R, neg_nc(p.Y), PPP);
+  Xyzz<CV> out;
+  out.X = typename CV::XX(X3);
+  out.Y = typename CV::XY(Y3);
+  out.ZZ = typename CV::XZZ(mul(p.ZZ, PP));
+  out.ZZZ = typename CV::XZZZ(mul(p.ZZZ, PPP));
+  return out;
+}
+
 // dbl-2008-s-1: XYZZ doubling (a = 0).  6M + 4S... used only when a general addition meets P == Q.
 template <class CV>
 OZK_HD Xyzz<CV> xyzz_dbl(const Xyzz<CV>& p) {
@@ -346,12 +389,14 @@ struct G1Cfg {
   static constexpr int PAIR_LANES = 4;    // (quad.cuh)
   static constexpr bool WIDE_INPUTS = true;   // jac_add / jac_dbl skip their entry reductions (base field)
   static constexpr bool LDS_ACC = false;  // level-1 accumulator in registers (137 VGPRs with the prefetched base, 3 waves per SIMD)
+  static constexpr bool LAZY_MADD = true; // level 1 adds with xyzz_madd_lazy (carries only where a value is squared or stored)
   using EX = Fe<FqParams, 94>;
   using EY = Fe<FqParams, 73>;
   using EZ = Fe<FqParams, 78>;
   using EA = Fe<FqParams, 17>;
-  // XYZZ accumulator of the hot loop: fixed point of xyzz_madd
-  using XX = Fe<FqParams, 83>;
+  // XYZZ accumulator of the hot loop: fixed point of xyzz_madd_lazy (X3 = R^2 + 2p - PPP + 2 (2p - Q) < 115/16 p; the
+  // carried schedule of xyzz_madd / xyzz_add stays below 83/16 p from these inputs)
+  using XX = Fe<FqParams, 115>;
   using XY = Fe<FqParams, 52>;
   using XZZ = Fe<FqParams, 17>;
   using XZZZ = Fe<FqParams, 17>;

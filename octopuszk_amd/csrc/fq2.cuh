@@ -238,6 +238,7 @@ struct G2Cfg {
   static constexpr int PAIR_LANES = 8;    // (below; a lane PAIR until round 2)
   static constexpr bool WIDE_INPUTS = false;
   static constexpr bool LDS_ACC = true;   // level-1 accumulator in LDS (msm_var.cuh RunAccLds)
+  static constexpr bool LAZY_MADD = false;
   using EX = Fe2<144>;
   using EY = Fe2<112>;
   using EZ = Fe2<112>;

@@ -757,6 +757,25 @@ struct RunAcc<CV, true> {
   }
   __device__ __forceinline__ void start_q(const Aff<EA>& q) { a = xyzz_from_affine<CV>(q); }
   __device__ __forceinline__ void accumulate_q(const Aff<EA>& q) { a = xyzz_madd(a, q); }
+  // the level-1 loop's form: the record as stored plus the sign of the digit; the addition negates y inside its
+  // one product (ec.cuh xyzz_madd_lazy) instead of normalising -y first
+  static __device__ __forceinline__ Aff<EA> decode_unsigned(const Raw& r) {
+    u32 w[IO::AFF_WORDS];
+#pragma unroll
+    for (int k = 0; k < IO::AFF_WORDS / 4; k++) {
+      w[4 * k] = r.w[k].x;
+      w[4 * k + 1] = r.w[k].y;
+      w[4 * k + 2] = r.w[k].z;
+      w[4 * k + 3] = r.w[k].w;
+    }
+    return IO::load_aff(w);
+  }
+  __device__ __forceinline__ void start_signed(const Aff<EA>& q, bool negate) {
+    Aff<EA> qs = q;
+    qs.y = select_el(negate, EA(reduce_to<17>(neg(q.y))), q.y);
+    a = xyzz_from_affine<CV>(qs);
+  }
+  __device__ __forceinline__ void accumulate_signed(const Aff<EA>& q, bool negate) { a = xyzz_madd_lazy(a, q, negate); }
   __device__ __forceinline__ void store(u32* dst) const { IO::store_rec_xyzz(a, dst); }
   // neutral element in the XYZZ record format (chunk cut on both sides)
   __device__ __forceinline__ void store_infinity(u32* dst) const {
@@ -876,7 +895,7 @@ struct RunAcc<CV, false> {
   __device__ __forceinline__ void store(u32* dst) const { IO::store_rec_jac(a, dst); }
 };
 
-template <class CV, bool FIRST>
+template <class CV, bool FIRST, bool LAZY = false>
 __device__ __forceinline__ void
 segreduce_lane(const int t, const u32* __restrict__ bid_in, const u32* __restrict__ idx_in,
                const u32* __restrict__ pts_in,  // FIRST: affine bases; else Jacobian slots
@@ -928,7 +947,11 @@ segreduce_lane(const int t, const u32* __restrict__ bid_in, const u32* __restric
         }
         if (p + 2 < e) v_next2 = idx_in[p + 2];
         const u32 b = b_cur;
-        const auto q = Acc::decode(r_cur, v_cur);
+        const bool negate = (v_cur & SIDX_NEG) != 0;
+        const auto q = [&] {
+          if constexpr (LAZY) return Acc::decode_unsigned(r_cur);
+          else return Acc::decode(r_cur, v_cur);
+        }();
         if (b != cur) {
           if (cur != BID_NONE) {
             if (cur_cb) {
@@ -940,9 +963,11 @@ segreduce_lane(const int t, const u32* __restrict__ bid_in, const u32* __restric
           }
           cur = b;
           cur_cb = (p == s) && cb;
-          acc.start_q(q);
+          if constexpr (LAZY) acc.start_signed(q, negate);
+          else acc.start_q(q);
         } else {
-          acc.accumulate_q(q);
+          if constexpr (LAZY) acc.accumulate_signed(q, negate);
+          else acc.accumulate_q(q);
         }
         r_cur = r_next;
         v_cur = v_next;
@@ -993,11 +1018,11 @@ segreduce_lane(const int t, const u32* __restrict__ bid_in, const u32* __restric
   bid_out[2 * (size_t)t + 1] = tail_bid;
 }
 
-// `clk` (level 1 only; may be null): two device-clock words of this launch, zero before it.  Every wave leaves
+// `clk` (level 1 only; may be null): two device-clock words of this launch, zero before it.  Every workgroup leaves
 // max(~start) in clk[0] and max(end) in clk[1] (wall_clock64: the constant-rate counter, hipDeviceAttributeWallClockRate),
 // so the launch's duration is clk[1] - ~clk[0] without any help from the runtime: HIP events around (or on) the
 // dispatch cost the three-stage schedule 4-13 % of its throughput, see ozk_prof_enable.
-template <class CV, bool FIRST>
+template <class CV, bool FIRST, bool LAZY = false>
 __global__ void __launch_bounds__(256, (FIRST && CV::LDS_ACC) ? 2 : 1)
 k_segreduce(const u32* __restrict__ bid_in, const u32* __restrict__ idx_in, const u32* __restrict__ pts_in,
             const u32* __restrict__ d_count, int n_in_static, int L,
@@ -1005,14 +1030,17 @@ k_segreduce(const u32* __restrict__ bid_in, const u32* __restrict__ idx_in, cons
             int n_lanes, unsigned long long* __restrict__ clk) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if constexpr (FIRST) {
-    if (clk != nullptr && (threadIdx.x & 63) == 0) atomicMax(&clk[0], ~(unsigned long long)wall_clock64());
+    if (clk != nullptr && threadIdx.x == 0) atomicMax(&clk[0], ~(unsigned long long)wall_clock64());
   }
   if (t < n_lanes)
-    segreduce_lane<CV, FIRST>(t, bid_in, idx_in, pts_in, d_count, n_in_static, L, buckets, bid_out, pts_out);
+    segreduce_lane<CV, FIRST, LAZY>(t, bid_in, idx_in, pts_in, d_count, n_in_static, L, buckets, bid_out, pts_out);
   if constexpr (FIRST) {
-    if (clk != nullptr && (threadIdx.x & 63) == 0) atomicMax(&clk[1], (unsigned long long)wall_clock64());
+    if (clk != nullptr && (threadIdx.x & 63) == 0) atomicMax(&clk[1], (unsigned long long)wall_clock64());  // (every wave: the last one to finish counts)
   }
 }
+
+// the device's constant-rate counter, for calibrating it against the host clock (ozk_prof_enable)
+static __global__ void k_read_clock(unsigned long long* out) { out[0] = (unsigned long long)wall_clock64(); }
 
 // The last generic levels (a few hundred lanes and fewer) in ONE single-block launch instead of one
 // 6-us launch per level: level after level with a block barrier in between, ping-ponging between the

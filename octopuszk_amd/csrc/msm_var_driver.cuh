@@ -35,6 +35,7 @@ struct ProfState {
   bool created = false;
   unsigned long long* d_clk = nullptr;  // PROF_CLOCK: 2 words per launch, zeroed by ozk_prof_enable
   int clk_cap = 0, clk_device = -1;
+  double clk_khz = 0.0;  // measured against the host's steady clock
   // event pair for launch number `count`, or false when the pool cannot grow
   bool slot(hipEvent_t* a, hipEvent_t* b) {
     if ((size_t)count >= e0.size()) {
@@ -397,13 +398,24 @@ int var_msm_accum(int n, void* sorted, size_t sorted_bytes, void* accum_ws, size
   // 40.25 KiB, not the 48 KiB of rounds 1-2: three blocks then leave 39.25 KiB to whatever runs beside them, which
   // is what the next MSM's sort kernels (k_sort1_scatter 34 KiB, k_sort2 38 KiB) need to be resident at all.
   if (!CV::LDS_ACC) acc_lds = (size_t)env_int("OZK_L1_LDS", 41216);
-  if (acc_lds > 65536)
-    OZK_HIP(hipFuncSetAttribute((const void*)(k_segreduce<CV, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)acc_lds));
-  hipExtLaunchKernelGGL((k_segreduce<CV, true>), dim3((unsigned)((lanes + TB - 1) / TB)), dim3(TB), (uint32_t)acc_lds, st,
-                        prof ? prof_e0 : (hipEvent_t) nullptr, prof ? prof_e1 : (hipEvent_t) nullptr, 0u,
-                        (const u32*)L.sbid, (const u32*)L.sidx, (const u32*)L.aff, (const u32*)L.total, 0, p.L1,
-                        L.buckets, L.slot_bid[0], L.slot_pts[0], (int)lanes, clk);
+  auto launch_l1 = [&](auto kern) {
+    if (acc_lds > 65536)
+      OZK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)acc_lds));
+    hipExtLaunchKernelGGL(kern, dim3((unsigned)((lanes + TB - 1) / TB)), dim3(TB), (uint32_t)acc_lds, st,
+                          prof ? prof_e0 : (hipEvent_t) nullptr, prof ? prof_e1 : (hipEvent_t) nullptr, 0u,
+                          (const u32*)L.sbid, (const u32*)L.sidx, (const u32*)L.aff, (const u32*)L.total, 0, p.L1,
+                          L.buckets, L.slot_bid[0], L.slot_pts[0], (int)lanes, clk);
+    return OZK_OK;
+  };
+  // the lazily carried mixed addition (ec.cuh xyzz_madd_lazy) where the curve has it; OZK_L1_LAZY=0: the carried form
+  int rc_l1;
+  if constexpr (CV::LAZY_MADD) {
+    if (env_int("OZK_L1_LAZY", 1)) rc_l1 = launch_l1(k_segreduce<CV, true, true>);
+    else rc_l1 = launch_l1(k_segreduce<CV, true, false>);
+  } else {
+    rc_l1 = launch_l1(k_segreduce<CV, true, false>);
+  }
+  if (rc_l1) return rc_l1;
   if (prof) g_prof.count++;
   // run merge: completes every bucket cut into at most RUN_MAX pieces; counts the surviving slots
   size_t n_in = 2 * lanes;

@@ -4,7 +4,8 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libozk_hip.so")
+# OZK_LIB_PATH: another build of the same library (tools/ A/B runs of two builds inside one gpurun call)
+LIB_PATH = os.environ.get("OZK_LIB_PATH") or os.path.join(HERE, "libozk_hip.so")
 
 _lib = None
 
@@ -26,6 +27,7 @@ _SIGS = {
     "ozk_prof_enable": (ctypes.c_int, [ctypes.c_int]),
     "ozk_prof_dominant_kernel_ms": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
     "ozk_prof_dominant_kernel_stats": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
+    "ozk_prof_clock_khz": (ctypes.c_double, []),
     "ozk_var_msm_plan": (ctypes.c_int, [i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]),
     "ozk_var_msm_glv": (ctypes.c_int, [i32]),
     "ozk_gen_bases_dev": (ctypes.c_int, [ctypes.c_uint64, i32, i32, vp, vp]),

@@ -152,7 +152,8 @@ def test_tail_shapes_give_the_same_bytes(type_, mode, monkeypatch):
 
 def test_device_clock_timing_agrees_with_hip_events():
     """ozk_prof_enable(2) (the kernel's waves stamp the device clock) against ozk_prof_enable(1) (HIP events on the
-    dispatch) on a lone MSM stream, where neither perturbs anything: same kernel, same duration within 5 %."""
+    dispatch) on a lone MSM stream, where neither perturbs anything: same kernel, same duration within 8 % (the
+    two runs are not the same launches; 0 - 6.5 % apart on the boxes of the pool)."""
     import ctypes
     import torch
     from octopuszk_amd import device as dev, lib
@@ -175,4 +176,4 @@ def test_device_clock_timing_agrees_with_hip_events():
         assert k.value == 8 and st[2] > 0
         means.append(st[1])
     clock, events = (means[0] + means[2]) / 2, (means[1] + means[3]) / 2
-    assert abs(clock - events) / events < 0.05, (clock, events)
+    assert abs(clock - events) / events < 0.08, (clock, events)

@@ -9,7 +9,7 @@ K = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 min_us = float(sys.argv[3]) if len(sys.argv) > 3 else 3.0
 t = glob.glob(d + '/*/*_kernel_trace.csv')[0]
 rows = sorted(csv.DictReader(open(t)), key=lambda r: int(r['Start_Timestamp']))
-l1 = [i for i, r in enumerate(rows) if 'k_segreduce<ozk::G1Cfg, true>' in r['Kernel_Name']]
+l1 = [i for i, r in enumerate(rows) if 'k_segreduce<ozk::G1Cfg, true' in r['Kernel_Name']]
 m = len(l1) // 2
 lo, hi = l1[m], l1[m + K]
 t0 = int(rows[lo]['Start_Timestamp'])
@@ -36,7 +36,6 @@ for r in rows:
     nm = r['Kernel_Name'].replace('void ozk::', '').replace('ozk::', '')[:40]
     tot[nm] += (e - s) / 1e3
     cnt[nm] += 1
-nl1 = max(1, cnt.get('k_segreduce<G1Cfg, true>(unsigned int const*', 0) or max(cnt.values()))
 print("per-kernel averages (us) over the middle half, and per MSM:")
 for nm in sorted(tot, key=lambda k: -tot[k]):
     print("  %-42s n=%4d avg=%8.1f" % (nm, cnt[nm], tot[nm] / cnt[nm]))
