@@ -156,7 +156,11 @@ def main():
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # OZK_BENCH_FORCE_COLLECTIVE=1 (tests only): take the N > 1 code path — init_process_group("nccl"), the RCCL
+    # all-gather of the partial and the HIP point sum inside every step — with a world of one, so that it runs on
+    # hardware on a one-GPU box (the sum of one affine point is that point)
+    force_coll = os.environ.get("OZK_BENCH_FORCE_COLLECTIVE", "0") == "1" and "RANK" in os.environ
+    if world > 1 or force_coll:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             dist.init_process_group("gloo")
@@ -191,15 +195,16 @@ def main():
         # Issued on the pipeline's side stream (behind the tail it consumes), so the single-lane
         # point sum does not sit between two heads on the main stream.
         three = isinstance(pipe, dev.VarMsmPipeline3)
-        if world == 1 and not three:
+        solo = world == 1 and not force_coll
+        if solo and not three:
             return pipe.result(ticket)
         # three-stage schedule: the caller's stream is the SORT stream and must not wait for a tail, so the result
         # is taken on the stream that ran this ticket's tail (the final barrier synchronises the device)
         side = pipe.stream_of(ticket) if three else pipe.side
         with torch.cuda.stream(side):
-            if world == 1:
+            if solo:
                 return pipe.result(ticket)
-            out = ozk_dist.distributed_var_msm(lambda: pipe.result(ticket), dev.points_sum, 1)
+            out = ozk_dist.distributed_var_msm(lambda: pipe.result(ticket), dev.points_sum, 1, always_collective=force_coll)
             done = torch.cuda.Event()
             done.record(side)
         finish.last_event = done
@@ -220,7 +225,7 @@ def main():
             issued[0] += 1
             with torch.cuda.stream(sts[i]):
                 res = ozk_dist.distributed_var_msm(lambda: wss[i].run(msm_bases, scalars, prepared=args.prepared),
-                                                   dev.points_sum, 1)
+                                                   dev.points_sum, 1, always_collective=force_coll)
         return res
 
     def run_steps(k):
@@ -388,10 +393,11 @@ def main():
                            "single_msm_latency_ms": round(single_ms, 3),
                            "three_streams_Mscalar_mul_s": streams3,
                            "result_hex": result_bytes.hex(),
-                           "parallelism": "index-range shard x%d, RCCL all-gather of 192-B partials + HIP point sum" % world},
+                           "parallelism": "index-range shard x%d, RCCL all-gather of 192-B partials + HIP point sum" % world,
+                           "collective_backend": (dist.get_backend() if dist.is_initialized() else None)},
                 "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or force_coll:
         dist.destroy_process_group()
 
 

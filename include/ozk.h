@@ -74,8 +74,9 @@ int ozk_var_double_msm_host(const uint8_t* bases_g1, const uint8_t* bases_g2,
  * Spark partition per device, VariableBaseMSM.java:775-786): the index range is cut into `shards` contiguous
  * slices (<= 0: one per visible device), slice i runs on device i % count from its own host thread, the
  * partial results are added on device 0.  Same bytes out as ozk_var_msm_host.  ozk_var_msm_auto_host is what
- * the JNI shim calls: sharded when several devices are visible and n >= OZK_SHARD_MIN_N (2^21), else
- * ozk_var_msm_host. */
+ * the JNI shim calls: ozk_var_msm_host on device taskID % count, as the reference; with OZK_SHARD=1 (opt-in, for a
+ * serial prover that is the only caller) calls of n >= OZK_SHARD_MIN_N (2^21) pairs are sharded over the visible
+ * devices instead.  Unverified on multi-GPU hardware (every box seen so far had one GPU). */
 int ozk_var_msm_sharded_host(const uint8_t* bases, const uint8_t* scalars, int32_t n, int32_t type, int32_t shards,
                              uint8_t* out);
 int ozk_var_msm_auto_host(const uint8_t* bases, const uint8_t* scalars, int32_t n, int32_t type, int32_t task_id,
@@ -104,9 +105,9 @@ int ozk_var_msm_dev(const void* d_bases, const void* d_scalars, int32_t n, int32
 int ozk_bases_create_host(const uint8_t* bases, int32_t n, int32_t type, int32_t task_id, void** handle);
 int ozk_var_msm_bases_host(void* handle, const uint8_t* scalars, int32_t n, uint8_t* out);
 int ozk_bases_destroy(void* handle);
-/* OZK_G1 / OZK_G2 for a live handle, 0 for a stale or released one (handles are validated by a magic
- * word; ozk_bases_destroy keeps the 100-byte header allocated so that a late call fails with
- * OZK_E_INVALID instead of touching freed memory). */
+/* OZK_G1 / OZK_G2 for a live handle, 0 for a stale or released one.  A handle is a token into a generation-
+ * checked table, not a pointer: a late call with a released (or forged) handle fails with OZK_E_INVALID, and
+ * ozk_bases_destroy really frees everything — at once, or when the MSM still running on the handle returns. */
 int ozk_bases_type(void* handle);
 size_t ozk_var_msm_prepared_bytes(int32_t n, int32_t type);
 int ozk_var_msm_prepare_dev(const void* d_bases, int32_t n, int32_t type, void* d_prepared, size_t prepared_size,

@@ -17,6 +17,10 @@
 //    elements in LDS (limb-major, conflict-free) for K stages with NO modular reduction
 //    between stages (value bounds are tracked at compile time), reads/writes HBM once,
 //    in >= 128-byte contiguous segments.  The bit reversal is fused into the first pass.
+#include <algorithm>
+#include <new>
+#include <vector>
+
 #include "curve.cuh"
 #include "host_ctx.h"
 
@@ -531,8 +535,12 @@ static int fft_core(const u32* d_in, int n, const u32* tw, u32* d_out, int out_s
 // first call with a given (device, n, omega[, g]) and kept in library-owned HBM: a prover transforms over ONE
 // domain, seven times per proof (R1CStoQAP.java:163-230), and rebuilding the table was 55 us of a 0.67 ms
 // transform at 2^22 and ~0.2 ms of the 2.4 ms witness map at 2^21.  (The reference recomputes two modular
-// exponentiations per butterfly, algebra_fft_FFTAuxiliary.cu:127,138.)  Four plans, least recently used out;
-// an evicted plan's memory is released with hipFree, which waits for the kernels that may still read it.
+// exponentiations per butterfly, algebra_fft_FFTAuxiliary.cu:127,138.)  Four plans PER DEVICE, least recently
+// used out.  A plan is PINNED (refcount) from plan_get until the caller has enqueued its last kernel that reads it
+// (PlanPin); only unpinned plans are evicted, and an evicted plan's memory is released with hipFree, which waits
+// for the kernels already enqueued.  (Round 2 kept four slots for the whole process and handed out raw pointers
+// into them: eight GPUs, or five concurrent domains, evicted each other's tables between plan_get and the launches.)
+// When every plan of a device is pinned the cache grows past four and shrinks again on release.
 // OZK_FFT_PLAN_CACHE=0 builds the tables per call in the caller's workspace, as round 1 did.
 struct QapConsts;
 struct FftPlan {
@@ -544,34 +552,62 @@ struct FftPlan {
   QapConsts* consts = nullptr;
   hipEvent_t ready = nullptr;
   unsigned long long last_use = 0;
+  int refs = 0;  // callers between plan_get and plan_release
 };
-constexpr int FFT_PLANS = 4;
+constexpr int FFT_PLANS = 4;  // per device
 static pthread_mutex_t g_plan_mu = PTHREAD_MUTEX_INITIALIZER;
-static FftPlan g_plans[FFT_PLANS];
+static std::vector<FftPlan*> g_plans;  // guarded by g_plan_mu
 static unsigned long long g_plan_clock = 0;
 
-static void plan_free(FftPlan& p) {
-  if (p.mem) {
-    hipSetDevice(p.device);
-    hipFree(p.mem);
+// (g_plan_mu held) releases the plan's device memory; the caller's current device is restored
+static void plan_free(FftPlan* p) {
+  int cur = 0;
+  const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+  if (p->mem) {
+    hipSetDevice(p->device);
+    hipFree(p->mem);
   }
-  if (p.ready) hipEventDestroy(p.ready);
-  p = FftPlan();
+  if (p->ready) hipEventDestroy(p->ready);
+  if (have_cur) hipSetDevice(cur);
+  delete p;
 }
 
-// returns the cached plan for (current device, n, omega[, g]) with its build enqueued on `st` if it is new;
-// *out stays valid until FFT_PLANS other domains have been used
+// returns the cached plan for (current device, n, omega[, g]), PINNED, with its build enqueued on `st` if it is
+// new; the caller releases it (plan_release / PlanPin) after enqueueing the last kernel that reads the tables
 static int plan_get(int n, const uint8_t* omega, const uint8_t* g, hipStream_t st, FftPlan** out);
+static void plan_release(FftPlan* p) {
+  pthread_mutex_lock(&g_plan_mu);
+  p->refs--;
+  // a cache that had to grow because every plan was pinned shrinks back here
+  int on_dev = 0;
+  for (FftPlan* q : g_plans) on_dev += q->device == p->device;
+  if (on_dev > FFT_PLANS && p->refs == 0) {
+    FftPlan* victim = nullptr;
+    for (FftPlan* q : g_plans)
+      if (q->device == p->device && q->refs == 0 && (!victim || q->last_use < victim->last_use)) victim = q;
+    if (victim) {
+      g_plans.erase(std::find(g_plans.begin(), g_plans.end(), victim));
+      plan_free(victim);
+    }
+  }
+  pthread_mutex_unlock(&g_plan_mu);
+}
+struct PlanPin {
+  FftPlan* p = nullptr;
+  ~PlanPin() {
+    if (p) plan_release(p);
+  }
+};
 
 static int fft_dev(const void* d_in, int n, const uint8_t* omega_host, void* d_out, void* wsp, size_t wsb,
                    hipStream_t st, int out_stride = 16) {
   const FftLayout L = fft_layout(n, wsp, wsb);
   if (L.bytes > wsb) return fail(OZK_E_INVALID, "workspace too small: need %zu bytes, got %zu", L.bytes, wsb);
   if (n >= 2 && env_int("OZK_FFT_PLAN_CACHE", 1)) {
-    FftPlan* pl = nullptr;
-    int rc = plan_get(n, omega_host, nullptr, st, &pl);
+    PlanPin pin;
+    int rc = plan_get(n, omega_host, nullptr, st, &pin.p);
     if (rc) return rc;
-    return fft_core((const u32*)d_in, n, pl->tw_f, (u32*)d_out, out_stride, L.buf[0], L.buf[1], st);
+    return fft_core((const u32*)d_in, n, pin.p->tw_f, (u32*)d_out, out_stride, L.buf[0], L.buf[1], st);
   }
   OZK_HIP(hipMemcpyAsync(L.omega, omega_host, 32, hipMemcpyHostToDevice, st));
   fft_build_twiddles(L.omega, n, L.small, L.tw, st);
@@ -729,19 +765,29 @@ static int plan_get(int n, const uint8_t* omega, const uint8_t* g, hipStream_t s
   OZK_HIP(hipGetDevice(&dev));
   pthread_mutex_lock(&g_plan_mu);
   FftPlan* hit = nullptr;
-  FftPlan* victim = &g_plans[0];
-  for (auto& p : g_plans) {
-    if (p.mem && p.device == dev && p.n == n && p.qap == (g != nullptr) && memcmp(p.omega, omega, 32) == 0 &&
-        (!g || memcmp(p.g, g, 32) == 0)) {
-      hit = &p;
+  FftPlan* victim = nullptr;  // least recently used UNPINNED plan of this device
+  int on_dev = 0;
+  for (FftPlan* p : g_plans) {
+    if (p->device != dev) continue;
+    on_dev++;
+    if (p->n == n && p->qap == (g != nullptr) && memcmp(p->omega, omega, 32) == 0 && (!g || memcmp(p->g, g, 32) == 0)) {
+      hit = p;
       break;
     }
-    if (!p.mem || (victim->mem && p.last_use < victim->last_use)) victim = &p;
+    if (p->refs == 0 && (!victim || p->last_use < victim->last_use)) victim = p;
   }
   int rc = OZK_OK;
   if (!hit) {
-    plan_free(*victim);
-    FftPlan& p = *victim;
+    if (on_dev >= FFT_PLANS && victim) {  // (all pinned: grow; plan_release shrinks the cache again)
+      g_plans.erase(std::find(g_plans.begin(), g_plans.end(), victim));
+      plan_free(victim);
+    }
+    FftPlan* np = new (std::nothrow) FftPlan();
+    if (!np) {
+      pthread_mutex_unlock(&g_plan_mu);
+      return fail(OZK_E_NOMEM, "out of host memory");
+    }
+    FftPlan& p = *np;
     p.device = dev;
     p.n = n;
     p.qap = g != nullptr;
@@ -772,7 +818,7 @@ static int plan_get(int n, const uint8_t* omega, const uint8_t* g, hipStream_t s
     hipError_t e = hipMalloc((void**)&p.mem, bytes);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p.ready, hipEventDisableTiming);
     if (e != hipSuccess) {
-      plan_free(p);
+      plan_free(np);
       pthread_mutex_unlock(&g_plan_mu);
       return fail(OZK_E_NOMEM, "FFT plan allocation (%zu bytes) failed: %s", bytes, hipGetErrorString(e));
     }
@@ -786,16 +832,22 @@ static int plan_get(int n, const uint8_t* omega, const uint8_t* g, hipStream_t s
     }
     if (!rc && hipEventRecord(p.ready, st) != hipSuccess) rc = fail(OZK_E_NO_DEVICE, "hipEventRecord failed");
     if (rc) {
-      plan_free(p);
+      plan_free(np);
       pthread_mutex_unlock(&g_plan_mu);
       return rc;
     }
-    hit = &p;
+    g_plans.push_back(np);
+    hit = np;
   }
   hit->last_use = ++g_plan_clock;
+  hit->refs++;
   hipEvent_t ev = hit->ready;
   pthread_mutex_unlock(&g_plan_mu);
-  OZK_HIP(hipStreamWaitEvent(st, ev, 0));   // a no-op on the stream that built it
+  const hipError_t we = hipStreamWaitEvent(st, ev, 0);   // a no-op on the stream that built it
+  if (we != hipSuccess) {
+    plan_release(hit);
+    return fail(OZK_E_NO_DEVICE, "hipStreamWaitEvent failed: %s", hipGetErrorString(we));
+  }
   *out = hit;
   return OZK_OK;
 }
@@ -804,10 +856,11 @@ static int qap_witness_dev(const void* d_A, const void* d_B, const void* d_C, in
                            const uint8_t* g_host, void* d_H, void* wsp, size_t wsb, hipStream_t st) {
   QapLayout L = qap_layout(m, wsp, wsb);
   if (L.bytes > wsb) return fail(OZK_E_INVALID, "workspace too small: need %zu bytes, got %zu", L.bytes, wsb);
+  PlanPin pin;  // held until the last launch below is enqueued
   if (env_int("OZK_FFT_PLAN_CACHE", 1)) {
-    FftPlan* pl = nullptr;
-    int prc = plan_get(m, omega_host, g_host, st, &pl);
+    int prc = plan_get(m, omega_host, g_host, st, &pin.p);
     if (prc) return prc;
+    FftPlan* pl = pin.p;
     L.consts = pl->consts;
     L.tw_f = pl->tw_f;
     L.tw_i = pl->tw_i;
@@ -955,7 +1008,14 @@ using namespace ozk;
 namespace ozk {
 void fft_plan_cache_release() {
   pthread_mutex_lock(&g_plan_mu);
-  for (auto& p : g_plans) plan_free(p);
+  for (size_t i = 0; i < g_plans.size();) {  // pinned plans (a call in flight on another thread) stay
+    if (g_plans[i]->refs == 0) {
+      plan_free(g_plans[i]);
+      g_plans.erase(g_plans.begin() + (long)i);
+    } else {
+      i++;
+    }
+  }
   pthread_mutex_unlock(&g_plan_mu);
 }
 }  // namespace ozk

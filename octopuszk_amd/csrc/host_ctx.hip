@@ -22,15 +22,17 @@ struct CopyPool {
   pthread_cond_t cv = PTHREAD_COND_INITIALIZER;
   CopyTask q[COPY_QUEUE];
   int head = 0, count = 0;
-  bool started = false, failed = false;
+  bool started = false, failed = false, stop = false;
+  int running = 0;
   pthread_t th[COPY_HELPERS];
 };
 CopyPool g_copy;
 
+// next queued piece; with `wait` a helper sleeps here until there is one, or until the pool is shut down (false)
 bool copy_pop(CopyTask* t, bool wait) {
   pthread_mutex_lock(&g_copy.mu);
   while (g_copy.count == 0) {
-    if (!wait) {
+    if (!wait || g_copy.stop) {
       pthread_mutex_unlock(&g_copy.mu);
       return false;
     }
@@ -43,9 +45,8 @@ bool copy_pop(CopyTask* t, bool wait) {
   return true;
 }
 void* copy_worker(void*) {
-  for (;;) {
-    CopyTask t;
-    copy_pop(&t, true);
+  CopyTask t;
+  while (copy_pop(&t, true)) {
     memcpy(t.dst, t.src, t.len);
     t.pending->fetch_sub(1, std::memory_order_release);
   }
@@ -53,14 +54,32 @@ void* copy_worker(void*) {
 }
 void copy_start_locked() {
   if (g_copy.started || g_copy.failed) return;
+  g_copy.stop = false;
+  g_copy.running = 0;
   for (int i = 0; i < COPY_HELPERS; i++) {
     if (pthread_create(&g_copy.th[i], nullptr, copy_worker, nullptr) != 0) {
       g_copy.failed = true;  // (already running helpers keep working; the caller copies the rest itself)
-      return;
+      break;
     }
-    pthread_detach(g_copy.th[i]);
+    g_copy.running++;
   }
-  g_copy.started = true;
+  g_copy.started = g_copy.running > 0;
+}
+// Stops and JOINS the helpers (ozk_host_cache_release, and the library's destructor: a JVM that unloads the
+// native library, or a dlclose, must not leave threads sleeping in unmapped text).  Callers in flight finish their
+// own pieces (parallel_memcpy drains the queue itself); the next call starts new helpers.
+void copy_shutdown() {
+  pthread_mutex_lock(&g_copy.mu);
+  const int n = g_copy.running;
+  g_copy.stop = true;
+  pthread_cond_broadcast(&g_copy.cv);
+  pthread_mutex_unlock(&g_copy.mu);
+  for (int i = 0; i < n; i++) pthread_join(g_copy.th[i], nullptr);
+  pthread_mutex_lock(&g_copy.mu);
+  g_copy.running = 0;
+  g_copy.started = false;
+  g_copy.failed = false;
+  pthread_mutex_unlock(&g_copy.mu);
 }
 void parallel_memcpy(void* dst, const void* src, size_t len) {
   static const int helpers = env_int("OZK_COPY_HELPERS", COPY_HELPERS);   // 0: the calling thread copies alone
@@ -272,8 +291,13 @@ namespace ozk {
 void fft_plan_cache_release();   // fft.hip
 }
 
+namespace {
+__attribute__((destructor)) void ozk_host_ctx_unload() { ozk::copy_shutdown(); }
+}  // namespace
+
 extern "C" int ozk_host_cache_release(void) {
   using namespace ozk;
+  copy_shutdown();
   fft_plan_cache_release();
   pthread_mutex_lock(&g_pool_mu);
   for (int d = 0; d < MAX_DEVICES; d++) {

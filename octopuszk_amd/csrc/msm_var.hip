@@ -89,45 +89,105 @@ int ozk_var_msm_prepared_dev(const void* d_prepared, const void* d_scalars, int3
   return var_msm_dev<G2Cfg>(nullptr, d_scalars, n, d_out, d_workspace, workspace_bytes, (hipStream_t)stream,
                             d_prepared);
 }
+// ---- handles of prepared bases: generation-checked table.  The value handed to the caller is a TOKEN
+// (generation << 32 | slot + 1), never a pointer: a stale or forged token resolves to nothing instead of to freed —
+// or recycled — memory, and a released handle's memory really is released (round 2 kept every dead handle's
+// header allocated for the life of the process so that late callers could be told apart).  A handle in use is
+// pinned by a reference count; the last user of a destroyed handle frees it.
+namespace {
+struct HandleSlot {
+  BasesHandle* h = nullptr;
+  uint32_t gen = 1;
+};
+pthread_mutex_t g_handle_mu = PTHREAD_MUTEX_INITIALIZER;
+std::vector<HandleSlot> g_handles;
+
+void bases_free(BasesHandle* h) {  // nobody else can reach h any more
+  hipSetDevice(h->device);
+  if (h->st) hipStreamSynchronize(h->st);
+  hipFree(h->d_prepared);
+  hipFree(h->d_scalars);
+  hipFree(h->d_out);
+  hipFree(h->d_ws);
+  if (h->st) hipStreamDestroy(h->st);
+  pthread_mutex_destroy(&h->mu);
+  free(h);
+}
+void* handle_publish(BasesHandle* h) {
+  pthread_mutex_lock(&g_handle_mu);
+  size_t i = 0;
+  for (; i < g_handles.size(); i++)
+    if (!g_handles[i].h) break;
+  if (i == g_handles.size()) g_handles.push_back(HandleSlot());
+  g_handles[i].h = h;
+  const uint64_t token = ((uint64_t)g_handles[i].gen << 32) | (uint64_t)(i + 1);
+  pthread_mutex_unlock(&g_handle_mu);
+  return (void*)(uintptr_t)token;
+}
+// token -> pinned handle (nullptr: stale, released or never issued); `unpublish` also retires the slot
+BasesHandle* handle_pin(void* token, bool unpublish = false) {
+  const uint64_t t = (uint64_t)(uintptr_t)token;
+  const uint64_t idx = (t & 0xffffffffull);
+  const uint32_t gen = (uint32_t)(t >> 32);
+  BasesHandle* h = nullptr;
+  pthread_mutex_lock(&g_handle_mu);
+  if (idx >= 1 && idx <= g_handles.size() && g_handles[idx - 1].h && g_handles[idx - 1].gen == gen) {
+    h = g_handles[idx - 1].h;
+    h->refs++;
+    if (unpublish) {
+      h->magic = 0;  // dead: freed by whoever drops the last reference
+      g_handles[idx - 1].h = nullptr;
+      if (++g_handles[idx - 1].gen == 0) g_handles[idx - 1].gen = 1;
+    }
+  }
+  pthread_mutex_unlock(&g_handle_mu);
+  return h;
+}
+void handle_unpin(BasesHandle* h) {
+  pthread_mutex_lock(&g_handle_mu);
+  const bool last = --h->refs == 0 && h->magic != BASES_MAGIC;
+  pthread_mutex_unlock(&g_handle_mu);
+  if (last) bases_free(h);
+}
+}  // namespace
+
 int ozk_bases_create_host(const uint8_t* bases, int32_t n, int32_t type, int32_t task_id, void** handle) {
   if (!bases || !handle) return fail(OZK_E_INVALID, "null pointer argument");
   if (n <= 0 || n > (1 << 24)) return fail(OZK_E_INVALID, "batch_size %d out of range [1, 2^24]", n);
   BasesHandle* h = nullptr;
   const int rc = type == OZK_G1 ? bases_create<G1Cfg>(bases, n, type, task_id, &h)
                                 : bases_create<G2Cfg>(bases, n, type, task_id, &h);
-  if (!rc) *handle = h;
-  return rc;
+  if (rc) return rc;
+  try {
+    *handle = handle_publish(h);
+  } catch (const std::exception&) {
+    bases_free(h);
+    return fail(OZK_E_NOMEM, "out of host memory");
+  }
+  return OZK_OK;
 }
 int ozk_var_msm_bases_host(void* handle, const uint8_t* scalars, int32_t n, uint8_t* out) {
   if (!handle || !scalars || !out) return fail(OZK_E_INVALID, "null pointer argument");
-  BasesHandle* h = (BasesHandle*)handle;
-  if (h->magic != BASES_MAGIC) return fail(OZK_E_INVALID, "not a live bases handle (stale or already released)");
-  if (n != h->n) return fail(OZK_E_INVALID, "batch_size %d does not match the prepared bases (%d)", n, h->n);
-  return h->type == OZK_G1 ? bases_msm<G1Cfg>(h, scalars, out) : bases_msm<G2Cfg>(h, scalars, out);
+  BasesHandle* h = handle_pin(handle);
+  if (!h) return fail(OZK_E_INVALID, "not a live bases handle (stale or already released)");
+  int rc;
+  if (n != h->n) rc = fail(OZK_E_INVALID, "batch_size %d does not match the prepared bases (%d)", n, h->n);
+  else rc = h->type == OZK_G1 ? bases_msm<G1Cfg>(h, scalars, out) : bases_msm<G2Cfg>(h, scalars, out);
+  handle_unpin(h);
+  return rc;
 }
 int ozk_bases_type(void* handle) {
-  BasesHandle* h = (BasesHandle*)handle;
-  if (!h || h->magic != BASES_MAGIC) return 0;
-  return h->type;
+  BasesHandle* h = handle ? handle_pin(handle) : nullptr;
+  if (!h) return 0;
+  const int t = h->type;
+  handle_unpin(h);
+  return t;
 }
 int ozk_bases_destroy(void* handle) {
   if (!handle) return OZK_OK;
-  BasesHandle* h = (BasesHandle*)handle;
-  if (h->magic != BASES_MAGIC) return fail(OZK_E_INVALID, "not a live bases handle (stale or already released)");
-  // wait for an MSM in flight on this handle, then mark it dead before anything is freed (the memory of
-  // the handle itself is kept: a late caller holding the stale pointer gets OZK_E_INVALID, not a crash)
-  pthread_mutex_lock(&h->mu);
-  h->magic = 0;
-  pthread_mutex_unlock(&h->mu);
-  hipSetDevice(h->device);
-  hipStreamSynchronize(h->st);
-  hipFree(h->d_prepared);
-  hipFree(h->d_scalars);
-  hipFree(h->d_out);
-  hipFree(h->d_ws);
-  hipStreamDestroy(h->st);
-  h->d_prepared = h->d_scalars = h->d_out = h->d_ws = nullptr;
-  h->st = nullptr;
+  BasesHandle* h = handle_pin(handle, true);
+  if (!h) return fail(OZK_E_INVALID, "not a live bases handle (stale or already released)");
+  handle_unpin(h);  // frees now, or when the MSM in flight on it returns
   return OZK_OK;
 }
 
@@ -328,20 +388,34 @@ int ozk_var_msm_sharded_host(const uint8_t* bases, const uint8_t* scalars, int32
   if (k > 64) k = 64;
   const size_t pt = type == OZK_G1 ? 96 : 192, ob = type == OZK_G1 ? 192 : 384;
   if (k == 1) return var_msm_shard(bases, scalars, n, type, 0, out);
-  std::vector<uint8_t> partial((size_t)k * ob);
-  std::vector<int> rcs(k, OZK_OK);
-  std::vector<std::string> msgs(k);
+  // (nothing may throw through the extern "C" boundary into a JVM: allocation and thread-start failures become codes)
+  std::vector<uint8_t> partial;
+  std::vector<int> rcs;
+  std::vector<std::string> msgs;
   std::vector<std::thread> th;
   const int base_n = n / k, rem = n % k;
-  for (int i = 0; i < k; i++) {
-    const size_t lo = (size_t)i * base_n + (size_t)(i < rem ? i : rem);
-    const int cnt = base_n + (i < rem ? 1 : 0);
-    th.emplace_back([&, i, lo, cnt] {
-      rcs[i] = var_msm_shard(bases + lo * pt, scalars + lo * 32, cnt, type, i, partial.data() + (size_t)i * ob);
-      if (rcs[i]) msgs[i] = err_buf();   // the message lives in that thread's buffer
-    });
+  int started = 0;
+  bool spawn_failed = false;
+  try {
+    partial.resize((size_t)k * ob);
+    rcs.assign(k, OZK_OK);
+    msgs.resize(k);
+    th.reserve(k);
+    for (int i = 0; i < k; i++) {
+      const size_t lo = (size_t)i * base_n + (size_t)(i < rem ? i : rem);
+      const int cnt = base_n + (i < rem ? 1 : 0);
+      th.emplace_back([&, i, lo, cnt] {
+        rcs[i] = var_msm_shard(bases + lo * pt, scalars + lo * 32, cnt, type, i, partial.data() + (size_t)i * ob);
+        if (rcs[i]) msgs[i] = err_buf();   // the message lives in that thread's buffer
+      });
+      started++;
+    }
+  } catch (const std::exception&) {  // std::system_error from the thread constructor, std::bad_alloc
+    spawn_failed = true;
   }
-  for (auto& t : th) t.join();
+  for (auto& t : th)
+    if (t.joinable()) t.join();
+  if (spawn_failed) return fail(OZK_E_NOMEM, "sharded MSM: could not start shard %d of %d (threads / host memory)", started, k);
   for (int i = 0; i < k; i++)
     if (rcs[i]) return fail(rcs[i], "shard %d of %d: %s", i, k, msgs[i].c_str());
   // sum of the partials on device 0
@@ -358,11 +432,15 @@ int ozk_var_msm_sharded_host(const uint8_t* bases, const uint8_t* scalars, int32
   return OZK_OK;
 }
 
-// What the JNI native calls: one GPU (taskID % count, as the reference) unless several are visible and the
-// call is large enough to be worth spreading (OZK_SHARD_MIN_N pairs, default 2^21; OZK_SHARD=0 disables).
+// What the JNI native calls: ONE GPU, taskID % count, as the reference (algebra_msm_VariableBaseMSM.cu:1249-1257) —
+// Spark runs one task per partition concurrently, so T task threads already cover the devices, and spreading every
+// call over all of them would multiply contexts and arenas by the device count.  A serial Java prover (one caller,
+// taskID 0) opts in to spreading its large calls with OZK_SHARD=1 (calls of at least OZK_SHARD_MIN_N pairs,
+// default 2^21, over OZK_SHARD_COUNT devices, default all).  The multi-device form has only ever run on a one-GPU
+// box (all slices on device 0): unverified on multi-GPU hardware.
 int ozk_var_msm_auto_host(const uint8_t* bases, const uint8_t* scalars, int32_t n, int32_t type, int32_t task_id,
                           uint8_t* out) {
-  if (env_int("OZK_SHARD", 1) && n >= env_int("OZK_SHARD_MIN_N", 1 << 21) && ozk_device_count() > 1)
+  if (env_int("OZK_SHARD", 0) && n >= env_int("OZK_SHARD_MIN_N", 1 << 21) && ozk_device_count() > 1)
     return ozk_var_msm_sharded_host(bases, scalars, n, type, env_int("OZK_SHARD_COUNT", 0), out);
   return ozk_var_msm_host(bases, scalars, n, type, task_id, out);
 }

@@ -707,6 +707,7 @@ int var_msm_prepare(const void* d_bases, int n, void* d_prepared, size_t bytes, 
 constexpr uint32_t BASES_MAGIC = 0x4f5a4b42u;  // "OZKB": set by create, cleared by destroy
 struct BasesHandle {
   uint32_t magic;
+  int refs;  // callers holding the handle (msm_var.hip, handle table)
   int device, n, type;
   hipStream_t st;
   uint8_t *d_prepared, *d_scalars, *d_out, *d_ws;

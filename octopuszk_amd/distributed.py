@@ -28,12 +28,14 @@ def all_gather_partials(partial: torch.Tensor, group=None) -> torch.Tensor:
     return out
 
 
-def distributed_var_msm(local_partial_fn, sum_fn, type_: int = 1, group=None) -> torch.Tensor:
+def distributed_var_msm(local_partial_fn, sum_fn, type_: int = 1, group=None, always_collective=False) -> torch.Tensor:
     """local_partial_fn() -> this rank's partial (wire-out bytes tensor);
     sum_fn(gathered, world, type_) -> the normalised sum.  The defaults used on GPUs are
-    device.VarMsmWorkspace.run and device.points_sum; tests inject CPU stand-ins over gloo."""
+    device.VarMsmWorkspace.run and device.points_sum; tests inject CPU stand-ins over gloo.
+    always_collective: run the all-gather and the point sum even in a world of one (how the RCCL code path is
+    exercised on a one-GPU box: the sum of one affine point is that point)."""
     partial = local_partial_fn()
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not always_collective):
         return partial
     gathered = all_gather_partials(partial, group)
     return sum_fn(gathered, dist.get_world_size(group), type_)

@@ -1,11 +1,16 @@
 """Host-side mirror of the reference's algebra.msm.FixedBaseMSM JNI path
-(FixedBaseMSM.java:49-66 getWindowSize, :186-315 batchMSM, :489-602 doubleBatchMSM,
-:753-785 batchFieldMSMPartition): same parameters, same byte formats; the natives are
-the C ABI of libozk_hip.so."""
+(FixedBaseMSM.java:49-66 getWindowSize, :186-315 batchMSM, :321-443 batchMSMPartition, :489-602 doubleBatchMSM,
+:753-785 batchFieldMSMPartition, :788-852 batchFilterFieldMSMPartition): same parameters, same chunking, same byte
+formats; the natives are the C ABI of libozk_hip.so."""
 import ctypes
 
 from . import lib as _lib
 from .variable_base_msm import big_integer_to_byte_array_cgbn, marshal_scalars
+
+G1_ITERATION_BATCH = 1 << 23       # FixedBaseMSM.java:200, :333
+G2_ITERATION_BATCH = 1 << 22       # FixedBaseMSM.java:257, :390
+DOUBLE_ITERATION_BATCH = 1 << 21   # FixedBaseMSM.java:511
+FR_MODULUS = 21888242871839275222246405745257275088548364400416034343698204186575808495617  # BN254aFrParameters
 
 G1_WINDOW_TABLE = [1, 5, 11, 32, 55, 162, 360, 815, 2373, 6978, 7122, 0, 57818, 0, 169679,
                    439759, 936073, 0, 4666555, 7580404, 0, 34552892]  # BN254aG1Parameters.java:25-50
@@ -65,19 +70,91 @@ def _be64(b: bytes) -> int:
     return int.from_bytes(b, "big")
 
 
-def batch_msm(scalar_size, window_size, base, scalars, is_g1=True, task_id=0):
-    """FixedBaseMSM.batchMSM (FixedBaseMSM.java:186-315): list of Jacobian integer points."""
-    outerc = (scalar_size + window_size - 1) // window_size
-    num_windows = scalar_size // window_size if scalar_size % window_size == 0 else scalar_size // window_size + 1
+def _base_wire(base, is_g1):
     if is_g1:
-        bw = b"".join(big_integer_to_byte_array_cgbn(c) for c in base)
-    else:
-        bw = b"".join(big_integer_to_byte_array_cgbn(base[i][j]) for i in range(3) for j in range(2))
-    raw = batch_msm_native_helper(outerc, window_size, num_windows, 1 << window_size, len(scalars), scalar_size,
-                                  bw, marshal_scalars(scalars), 1 if is_g1 else 2, task_id)
+        return b"".join(big_integer_to_byte_array_cgbn(c) for c in base)
+    return b"".join(big_integer_to_byte_array_cgbn(base[i][j]) for i in range(3) for j in range(2))
+
+
+def _points_be(raw, count, is_g1):
+    """count points of 3 (G1) / 6 (G2) 64-byte big-endian values (FixedBaseMSM.java:233-246, :286-305)"""
     out = []
     per = 192 if is_g1 else 384
-    for i in range(len(scalars)):
+    for i in range(count):
         v = [_be64(raw[per * i + 64 * k: per * i + 64 * (k + 1)]) for k in range(per // 64)]
         out.append(tuple(v) if is_g1 else ((v[0], v[1]), (v[2], v[3]), (v[4], v[5])))
     return out
+
+
+def batch_msm(scalar_size, window_size, base, scalars, is_g1=True, task_id=0):
+    """FixedBaseMSM.batchMSM (FixedBaseMSM.java:186-315): base * s_i for every scalar, as Jacobian integer points;
+    chunks of 2^23 (G1) / 2^22 (G2) scalars per native call, the window table rebuilt by each call."""
+    outerc = (scalar_size + window_size - 1) // window_size
+    num_windows = scalar_size // window_size if scalar_size % window_size == 0 else scalar_size // window_size + 1
+    step = G1_ITERATION_BATCH if is_g1 else G2_ITERATION_BATCH
+    bw = _base_wire(base, is_g1)
+    out = []
+    for it in range(0, len(scalars), step):
+        sc = scalars[it:it + step]
+        raw = batch_msm_native_helper(outerc, window_size, num_windows, 1 << window_size, len(sc), scalar_size,
+                                      bw, marshal_scalars(sc), 1 if is_g1 else 2, task_id)
+        out.extend(_points_be(raw, len(sc), is_g1))
+    return out
+
+
+def batch_msm_partition(scalar_size, window_size, out_size, in_size, base, indexed_scalars, is_g1=True, task_id=0):
+    """FixedBaseMSM.batchMSMPartition (FixedBaseMSM.java:321-443): a partition's list of (index, scalar) tuples ->
+    list of (index, point); the same chunking as batchMSM, the partition's taskID handed to the native."""
+    outerc = (scalar_size + window_size - 1) // window_size
+    step = G1_ITERATION_BATCH if is_g1 else G2_ITERATION_BATCH
+    bw = _base_wire(base, is_g1)
+    out = []
+    for it in range(0, len(indexed_scalars), step):
+        part = indexed_scalars[it:it + step]
+        raw = batch_msm_native_helper(outerc, window_size, out_size, in_size, len(part), scalar_size, bw,
+                                      marshal_scalars([p[1] for p in part]), 1 if is_g1 else 2, task_id)
+        pts = _points_be(raw, len(part), is_g1)
+        out.extend((part[i][0], pts[i]) for i in range(len(part)))
+    return out
+
+
+def double_batch_msm(out_size1, in_size1, out_size2, in_size2, scalar_size1, window_size1, base_g1, scalar_size2,
+                     window_size2, base_g2, scalars):
+    """FixedBaseMSM.doubleBatchMSM (FixedBaseMSM.java:489-602): (base_g1 * s_i, base_g2 * s_i) for every scalar.
+    Chunks of 2^21 scalars; per element the native returns NINE 64-byte big-endian values —
+    G1 (X, Y, Z) then G2 (Xa, Xb, Ya, Yb, Za, Zb) (FixedBaseMSM.java:557-591, algebra_msm_FixedBaseMSM.cu:1479-1482)."""
+    outerc1 = (scalar_size1 + window_size1 - 1) // window_size1
+    outerc2 = (scalar_size2 + window_size2 - 1) // window_size2
+    b1, b2 = _base_wire(base_g1, True), _base_wire(base_g2, False)
+    out = []
+    for it in range(0, len(scalars), DOUBLE_ITERATION_BATCH):
+        sc = scalars[it:it + DOUBLE_ITERATION_BATCH]
+        raw = double_batch_msm_native_helper(outerc1, window_size1, outerc2, window_size2, out_size1, in_size1,
+                                             out_size2, in_size2, len(sc), b1, b2, marshal_scalars(sc), 0)
+        for i in range(len(sc)):
+            v = [_be64(raw[(9 * i + k) * 64:(9 * i + k + 1) * 64]) for k in range(9)]
+            out.append(((v[0], v[1], v[2]), ((v[3], v[4]), (v[5], v[6]), (v[7], v[8]))))
+    return out
+
+
+def batch_field_msm_partition(base_element, indexed_scalars, task_id=0):
+    """FixedBaseMSM.batchFieldMSMPartition (FixedBaseMSM.java:753-785): x_i * base in Fr for a partition's list of
+    (index, x_i).  The native's input is the n scalars FOLLOWED BY THE BASE as element n (:765); its output n 64-byte
+    big-endian values, which setBigInteger reduces mod r (bn254a/BN254aFields.java:52-54)."""
+    data = marshal_scalars([p[1] for p in indexed_scalars]) + big_integer_to_byte_array_cgbn(base_element)
+    n = len(indexed_scalars)
+    raw = field_batch_msm_native_helper(data, n, task_id)
+    return [(indexed_scalars[i][0], _be64(raw[64 * i:64 * (i + 1)]) % FR_MODULUS) for i in range(n)]
+
+
+def batch_filter_field_msm_partition(inverse_delta, inverse_gamma, num_inputs, indexed_scalars, type_, task_id=0):
+    """FixedBaseMSM.batchFilterFieldMSMPartition (FixedBaseMSM.java:788-852): type_ 0 keeps the elements with
+    index < num_inputs and multiplies them by inverse_gamma, type_ 1 the others by inverse_delta; one native call
+    over the kept elements with the multiplier appended."""
+    keep = [p for p in indexed_scalars if (p[0] < num_inputs) == (type_ == 0)]
+    mult = inverse_gamma if type_ == 0 else inverse_delta
+    if not keep:
+        return []
+    return batch_field_msm_partition(mult, keep, task_id)
+
+

@@ -121,3 +121,39 @@ def test_fft_other_tile_geometries(tile, monkeypatch):
     finally:
         monkeypatch.delenv("OZK_FFT_TILE")
         L.ozk_tuning_reload()
+
+
+def test_fft_plan_cache_many_domains_from_many_threads():
+    """the plan cache handed out raw pointers into four process-wide slots.  Nine domains (more than the
+    four plans a device keeps) cycled from six host threads at once — every call must return what the same call
+    returns alone; the plans in use are pinned while their caller enqueues its kernels (csrc/fft.hip PlanPin)."""
+    import threading
+    from octopuszk_amd import fft as F, lib
+    rng = random.Random(99)
+    domains = []
+    for logn in (3, 5, 6, 8, 9, 10, 11, 12, 13):
+        n = 1 << logn
+        vals = [rng.randrange(F.FR) for _ in range(n)]
+        domains.append((vals, F.root_of_unity(n)))
+    alone = [F.serial_radix2_fft(v, w) for v, w in domains]
+    assert alone[0] == o.naive_dft(domains[0][0], domains[0][1]) and alone[3] == o.naive_dft(domains[3][0], domains[3][1])
+    errors = []
+
+    def worker(t):
+        try:
+            r = random.Random(t)
+            for it in range(40):
+                k = r.randrange(len(domains))
+                if F.serial_radix2_fft(domains[k][0], domains[k][1], task_id=t) != alone[k]:
+                    errors.append((t, it, k))
+        except Exception as e:   # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errors, errors[:5]
+    lib.load().ozk_host_cache_release()          # releases the unpinned plans and stops the copy helpers ...
+    assert F.serial_radix2_fft(domains[4][0], domains[4][1]) == alone[4]   # ... and the next call starts over
