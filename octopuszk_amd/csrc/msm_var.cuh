@@ -934,24 +934,30 @@ segreduce_lane(const int t, const u32* __restrict__ bid_in, const u32* __restric
       // word is already here) and the index word of entry p + 2 are in flight; nothing is computed on them
       // until they are consumed, so the dependent idx -> base chain never stalls the additions
       // (every entry of the sorted array is a live base index at this level)
-      u32 v_cur = idx_in[s];
-      u32 v_next = (s + 1 < e) ? idx_in[s + 1] : 0u;
-      typename Acc::Raw r_cur = Acc::load_raw(pts_in, v_cur);
+      // The look-ahead loads are UNCONDITIONAL (positions clamped to the chunk's last entry, which is simply read
+      // again): a load under `if (p + 1 < e)` makes every look-ahead register a phi of "loaded" and "kept", and the
+      // compiler then carries the whole 16-word record and the index words through ~45 v_mov per addition.
+      const u32 n_e = (u32)(e - s);         // entries of this chunk (<= L)
+      const u32* idx_c = idx_in + s;
+      const u32* bid_c = bid_in + s;
+      u32 v_cur = idx_c[0];
+      u32 v_next = idx_c[n_e > 1 ? 1 : 0];
+      typename Acc::Raw r = Acc::load_raw(pts_in, v_cur);
       u32 b_cur = first_bid;
-      for (long long p = s; p < e; p++) {
-        typename Acc::Raw r_next = r_cur;
-        u32 b_next = BID_NONE, v_next2 = 0u;
-        if (p + 1 < e) {
-          r_next = Acc::load_raw(pts_in, v_next);
-          b_next = bid_in[p + 1];
-        }
-        if (p + 2 < e) v_next2 = idx_in[p + 2];
+      for (u32 k = 0; k < n_e; k++) {
         const u32 b = b_cur;
         const bool negate = (v_cur & SIDX_NEG) != 0;
         const auto q = [&] {
-          if constexpr (LAZY) return Acc::decode_unsigned(r_cur);
-          else return Acc::decode(r_cur, v_cur);
+          if constexpr (LAZY) return Acc::decode_unsigned(r);
+          else return Acc::decode(r, v_cur);
         }();
+        // request entry k + 1's record and bucket id and entry k + 2's index word; consumed one iteration later
+        const u32 k1 = (k + 1 < n_e) ? k + 1 : n_e - 1;
+        const u32 k2 = (k + 2 < n_e) ? k + 2 : n_e - 1;
+        r = Acc::load_raw(pts_in, v_next);
+        b_cur = bid_c[k1];
+        v_cur = v_next;
+        v_next = idx_c[k2];
         if (b != cur) {
           if (cur != BID_NONE) {
             if (cur_cb) {
@@ -962,17 +968,13 @@ segreduce_lane(const int t, const u32* __restrict__ bid_in, const u32* __restric
             }
           }
           cur = b;
-          cur_cb = (p == s) && cb;
+          cur_cb = (k == 0) && cb;
           if constexpr (LAZY) acc.start_signed(q, negate);
           else acc.start_q(q);
         } else {
           if constexpr (LAZY) acc.accumulate_signed(q, negate);
           else acc.accumulate_q(q);
         }
-        r_cur = r_next;
-        v_cur = v_next;
-        v_next = v_next2;
-        b_cur = b_next;
       }
     } else {
     for (long long p = s; p < e; p++) {
