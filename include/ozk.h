@@ -269,6 +269,28 @@ size_t ozk_r1cs_evaluate_workspace_bytes(int32_t n_long);
 int ozk_r1cs_evaluate_dev(const void* d_row_ptr, const void* d_index, const void* d_coeff, const void* d_assignment,
                           int32_t rows, const void* d_long_rows, int32_t n_long, void* d_out, void* d_workspace,
                           size_t workspace_bytes, void* stream);
+/* ---------------- QAP instance of the setup (R1CStoQAP.R1CStoQAPRelation,
+ * reductions/r1cs_to_qap/R1CStoQAP.java:37-98; SerialSetup.java:50-74,146-151) — pieces, all device-resident:
+ *   ozk_qap_lagrange_dev    L_i(t) for the radix-2 domain of size m (FFTAuxiliary.serialRadix2LagrangeCoefficients,
+ *                           FFTAuxiliary.java:250-302; one shared inversion per 8 coefficients instead of m inversions)
+ *                           and Z(t) = t^m - 1.  t must not lie in the domain (t^m != 1: the caller checks).
+ *   ozk_sparse_mat_vec_dev  out = M v for a CSR matrix in HBM: At / Bt / Ct are the TRANSPOSED constraint matrices
+ *                           (input-consistency rows appended to A) times the Lagrange vector.  Same layout and
+ *                           long-row list as ozk_r1cs_evaluate_dev, without its rule for variable 0.
+ *   ozk_fr_powers_dev       out[i] = base^i k  (Ht, and the H query's scalars t^i Z / delta)
+ *   ozk_fr_lincomb3_dev     out[i] = (ka a_i + kb b_i + c_i) kk  (the gammaABC / deltaABC scalars)
+ * All vectors are n x 32-byte little-endian canonical values; 32-byte host arguments are LE canonical too. */
+size_t ozk_qap_lagrange_workspace_bytes(int32_t m);
+int ozk_qap_lagrange_dev(const uint8_t* t_host32, const uint8_t* omega_host32, int32_t m, void* d_out, void* d_zt,
+                         void* d_workspace, size_t workspace_bytes, void* stream);
+int ozk_sparse_mat_vec_dev(const void* d_row_ptr, const void* d_index, const void* d_coeff, const void* d_vec,
+                           int32_t rows, const void* d_long_rows, int32_t n_long, void* d_out, void* d_workspace,
+                           size_t workspace_bytes, void* stream);
+size_t ozk_fr_powers_workspace_bytes(int32_t n);
+int ozk_fr_powers_dev(const uint8_t* base_host32, const uint8_t* k_host32, int32_t n, void* d_out, void* d_workspace,
+                      size_t workspace_bytes, void* stream);
+int ozk_fr_lincomb3_dev(const void* d_a, const void* d_b, const void* d_c, int32_t n, const uint8_t* ka_host32,
+                        const uint8_t* kb_host32, const uint8_t* kk_host32, void* d_out, void* d_scratch96, void* stream);
 int ozk_qap_witness_host(const uint8_t* A, const uint8_t* B, const uint8_t* C, int32_t m, const uint8_t* omega,
                          const uint8_t* g, int32_t task_id, uint8_t* H);
 size_t ozk_qap_witness_workspace_bytes(int32_t m);

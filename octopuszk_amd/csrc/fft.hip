@@ -901,11 +901,14 @@ constexpr int R1CS_LONG = 64;
 using FrAcc = Fe<FrP, 32>;
 
 // value of one term (plain, < 2r): z[j], times its coefficient when there is a coefficient array
+// ONE0: LinearCombination.evaluate's rule for the variable "one" (constraint evaluation); without it the kernels
+// are a plain sparse matrix x vector product over Fr (the QAP instance of the setup, ozk_qap_instance_dev)
+template <bool ONE0>
 __device__ __forceinline__ Fe<FrP, 32> r1cs_term(const u32* __restrict__ idx, const u32* __restrict__ coeff,
                                                  const u32* __restrict__ z, u32 t) {
   using ET = ElemTraits<Fe<FrP, 17>>;
   const u32 j = idx[t];
-  if (j == 0) {
+  if (ONE0 && j == 0) {
     Fe<FrP, 32> one = Fe<FrP, 32>(fe_zero<FrP>());
     one.l[0] = 1;
     return one;
@@ -919,6 +922,7 @@ __device__ __forceinline__ Fe<FrP, 32> r1cs_term(const u32* __restrict__ idx, co
   return Fe<FrP, 32>(mul(x, cm));                         // plain product
 }
 
+template <bool ONE0>
 __global__ void __launch_bounds__(256) k_r1cs_eval(const u32* __restrict__ ptr, const u32* __restrict__ idx,
                                                    const u32* __restrict__ coeff, const u32* __restrict__ z, int rows,
                                                    u32* __restrict__ out) {
@@ -927,7 +931,7 @@ __global__ void __launch_bounds__(256) k_r1cs_eval(const u32* __restrict__ ptr, 
   const u32 b = ptr[row], e = ptr[row + 1];
   if (e - b > (u32)R1CS_LONG) return;
   FrAcc acc = FrAcc(fe_zero<FrP>());
-  for (u32 t = b; t < e; t++) acc = FrAcc(reduce_to<32>(add(acc, r1cs_term(idx, coeff, z, t))));
+  for (u32 t = b; t < e; t++) acc = FrAcc(reduce_to<32>(add(acc, r1cs_term<ONE0>(idx, coeff, z, t))));
   u32 o[8];
   pack(canonical(acc), o);
   uint4* dst = reinterpret_cast<uint4*>(out + (size_t)row * 8);
@@ -961,6 +965,7 @@ __device__ __forceinline__ FrAcc r1cs_block_sum(FrAcc acc, u32* part) {
   for (int i = 0; i < 9; i++) r.l[i] = part[i * 256];
   return r;
 }
+template <bool ONE0>
 __global__ void __launch_bounds__(256) k_r1cs_eval_long1(const u32* __restrict__ ptr, const u32* __restrict__ idx,
                                                          const u32* __restrict__ coeff, const u32* __restrict__ z,
                                                          const u32* __restrict__ long_rows, u32* __restrict__ partial) {
@@ -972,7 +977,7 @@ __global__ void __launch_bounds__(256) k_r1cs_eval_long1(const u32* __restrict__
   const u32 lo = b + sl * per;
   const u32 hi = (lo + per < e) ? lo + per : e;
   FrAcc acc = FrAcc(fe_zero<FrP>());
-  for (u32 t = lo + threadIdx.x; t < hi; t += 256) acc = FrAcc(reduce_to<32>(add(acc, r1cs_term(idx, coeff, z, t))));
+  for (u32 t = lo + threadIdx.x; t < hi; t += 256) acc = FrAcc(reduce_to<32>(add(acc, r1cs_term<ONE0>(idx, coeff, z, t))));
   const FrAcc r = r1cs_block_sum(acc, part);
   if (threadIdx.x == 0) {
     u32 o[8];
@@ -999,6 +1004,132 @@ __global__ void __launch_bounds__(256) k_r1cs_eval_long2(const u32* __restrict__
 #pragma unroll
     for (int i = 0; i < 8; i++) out[(size_t)row * 8 + i] = o[i];
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The QAP instance of the setup (R1CStoQAP.R1CStoQAPRelation, reductions/r1cs_to_qap/
+// R1CStoQAP.java:37-98): Lagrange coefficients of the domain at the secret point t
+// (FFTAuxiliary.serialRadix2LagrangeCoefficients, FFTAuxiliary.java:250-302), the powers t^i, and
+// At / Bt / Ct as sparse products over the TRANSPOSED constraint matrices (k_r1cs_eval<false> above).
+// Round 2 did all of it in Python integers: 4.3 s of a 5.7 s setup at 2^20 constraints.
+//
+// L_i(t) = (Z / m) omega^i / (t - omega^i), Z = t^m - 1 (t not in the domain: the caller checks t^m != 1).
+// A lane takes LAG_BATCH indices t, t + lanes, ... (interleaved: consecutive lanes write consecutive records) and
+// shares ONE inversion among their denominators (Montgomery's trick: the Java inverts m times, :295).
+// pw: two-level power table of omega (k_tw_small with lo = TW_LO, Montgomery form).
+constexpr int LAG_BATCH = 8;
+struct LagConsts {  // packed 8 words each, filled by k_lag_consts
+  u32 t_wire[8];    // t (plain canonical), uploaded by the host
+  u32 t_mont[8];    // t R
+  u32 c_mont[8];    // (t^m - 1) / m * R
+  u32 z_wire[8];    // t^m - 1 (plain): Zt of the QAP instance
+};
+__global__ void k_lag_consts(LagConsts* __restrict__ c, int m) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  u32 w[8], o[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) w[i] = c->t_wire[i];
+  const Fe<FrP, 32> t = Fe<FrP, 32>(to_mont<FrP>(w));
+  Fe<FrP, 32> tm = fe_one<FrP>();
+  const unsigned e = (unsigned)m;
+  for (int b = 31; b >= 0; b--) {
+    tm = Fe<FrP, 32>(sqr(tm));
+    if ((e >> b) & 1) tm = Fe<FrP, 32>(mul(tm, t));
+  }
+  const auto Z = sub(tm, fe_one<FrP>());
+  u32 mw[8] = {(u32)m, 0, 0, 0, 0, 0, 0, 0};
+  const auto mi = inv(to_mont<FrP>(mw));
+  pack(canonical(t), o);
+#pragma unroll
+  for (int i = 0; i < 8; i++) c->t_mont[i] = o[i];
+  pack(canonical(mul(Z, mi)), o);
+#pragma unroll
+  for (int i = 0; i < 8; i++) c->c_mont[i] = o[i];
+  from_mont(Z, o);
+#pragma unroll
+  for (int i = 0; i < 8; i++) c->z_wire[i] = o[i];
+}
+__global__ void __launch_bounds__(256) k_lagrange(const LagConsts* __restrict__ c, const u32* __restrict__ pw, int lo,
+                                                  int m, u32* __restrict__ out) {
+  using ET = ElemTraits<Fe<FrP, 16>>;
+  using E32 = Fe<FrP, 32>;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lanes = (m + LAG_BATCH - 1) / LAG_BATCH;
+  if (t >= lanes) return;
+  const auto tm = ET::load(c->t_mont);
+  const auto cm = ET::load(c->c_mont);
+  auto at = [&](int k) { return k * lanes + t; };
+  E32 prefix[LAG_BATCH], wpow[LAG_BATCH];
+  E32 run = E32(fe_one<FrP>());
+#pragma unroll
+  for (int k = 0; k < LAG_BATCH; k++) {
+    const int i = at(k);
+    if (i < m) {
+      wpow[k] = E32(mul(ET::load(pw + (size_t)(i % lo) * 8), ET::load(pw + (size_t)(lo + i / lo) * 8)));  // omega^i R
+      const auto d = reduce_to<32>(sub(tm, wpow[k]));                                                      // (t - omega^i) R
+      run = E32(mul(run, d));
+    }
+    prefix[k] = run;
+  }
+  E32 invrun = E32(inv(run));
+#pragma unroll
+  for (int k = LAG_BATCH - 1; k >= 0; k--) {
+    const int i = at(k);
+    if (i < m) {
+      E32 di = invrun;                                  // 1 / (t - omega^i), Montgomery form
+      if (k > 0) di = E32(mul(invrun, prefix[k - 1]));
+      invrun = E32(mul(invrun, reduce_to<32>(sub(tm, wpow[k]))));
+      u32 o[8];
+      from_mont(mul(mul(cm, wpow[k]), di), o);          // plain, canonical
+      uint4* dst = reinterpret_cast<uint4*>(out + (size_t)i * 8);
+      dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+      dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+    }
+  }
+}
+// out[i] = base^i * k for i < n, plain canonical (pw: two-level Montgomery power table of `base`; k_mont = k R).
+// The Ht = t^i of the QAP instance (R1CStoQAP.java:90-96) with k = 1, and the H query's scalars t^i Z / delta
+// (SerialSetup.java:146-151) with k = Z / delta, in one pass.
+__global__ void __launch_bounds__(256) k_powers_scaled(const u32* __restrict__ pw, int lo, int n,
+                                                       const u32* __restrict__ k_mont, u32* __restrict__ out) {
+  using ET = ElemTraits<Fe<FrP, 16>>;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const auto p = mul(ET::load(pw + (size_t)(i % lo) * 8), ET::load(pw + (size_t)(lo + i / lo) * 8));  // base^i R
+  Fe<FrP, 1> one = fe_zero<FrP>();
+  one.l[0] = 1;
+  u32 o[8];
+  pack(canonical(mul(mul(p, ET::load(k_mont)), one)), o);   // (base^i R)(k R)/R = base^i k R; /R -> plain
+  uint4* dst = reinterpret_cast<uint4*>(out + (size_t)i * 8);
+  dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+  dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+}
+// out[i] = (ka a[i] + kb b[i] + c[i]) kk, all plain canonical; ka, kb, kk: three Montgomery-form constants at k3
+// (the deltaABC / gammaABC scalars of the setup, SerialSetup.java:61-74)
+__global__ void __launch_bounds__(256) k_lincomb3(const u32* __restrict__ a, const u32* __restrict__ b,
+                                                  const u32* __restrict__ c, int n, const u32* __restrict__ k3,
+                                                  u32* __restrict__ out) {
+  using ET = ElemTraits<Fe<FrP, 16>>;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const auto x = ET::load(a + (size_t)i * 8), y = ET::load(b + (size_t)i * 8), z = ET::load(c + (size_t)i * 8);
+  const auto s = add(add(mul(x, ET::load(k3)), mul(y, ET::load(k3 + 8))), z);   // plain
+  u32 o[8];
+  pack(canonical(mul(reduce_to<32>(s), ET::load(k3 + 16))), o);
+  uint4* dst = reinterpret_cast<uint4*>(out + (size_t)i * 8);
+  dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+  dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+}
+// wire (plain canonical) constants -> Montgomery form, in place: one lane per 8-word element
+__global__ void k_to_mont_inplace(u32* __restrict__ v, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 w[8], o[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) w[k] = v[(size_t)i * 8 + k];
+  pack(canonical(to_mont<FrP>(w)), o);
+#pragma unroll
+  for (int k = 0; k < 8; k++) v[(size_t)i * 8 + k] = o[k];
 }
 
 }  // namespace ozk
@@ -1073,15 +1204,114 @@ int ozk_r1cs_evaluate_dev(const void* d_row_ptr, const void* d_index, const void
     return fail(OZK_E_INVALID, "workspace too small: need %zu bytes, got %zu", ozk_r1cs_evaluate_workspace_bytes(n_long),
                 workspace_bytes);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_r1cs_eval, dim3((rows + 255) / 256), dim3(256), 0, st, (const u32*)d_row_ptr, (const u32*)d_index,
+  hipLaunchKernelGGL(k_r1cs_eval<true>, dim3((rows + 255) / 256), dim3(256), 0, st, (const u32*)d_row_ptr, (const u32*)d_index,
                      (const u32*)d_coeff, (const u32*)d_assignment, rows, (u32*)d_out);
   if (n_long > 0) {
-    hipLaunchKernelGGL(k_r1cs_eval_long1, dim3(n_long * R1CS_SPLIT), dim3(256), 0, st, (const u32*)d_row_ptr,
+    hipLaunchKernelGGL(k_r1cs_eval_long1<true>, dim3(n_long * R1CS_SPLIT), dim3(256), 0, st, (const u32*)d_row_ptr,
                        (const u32*)d_index, (const u32*)d_coeff, (const u32*)d_assignment, (const u32*)d_long_rows,
                        (u32*)d_workspace);
     hipLaunchKernelGGL(k_r1cs_eval_long2, dim3(n_long), dim3(256), 0, st, (const u32*)d_long_rows,
                        (const u32*)d_workspace, (u32*)d_out);
   }
+  OZK_HIP(hipGetLastError());
+  return OZK_OK;
+}
+
+// out = M x v over Fr for a CSR matrix resident in HBM (the same kernels as ozk_r1cs_evaluate_dev without the rule
+// for variable 0): the QAP instance uses it on the transposed constraint matrices with v = the Lagrange coefficients
+int ozk_sparse_mat_vec_dev(const void* d_row_ptr, const void* d_index, const void* d_coeff, const void* d_vec,
+                           int32_t rows, const void* d_long_rows, int32_t n_long, void* d_out, void* d_workspace,
+                           size_t workspace_bytes, void* stream) {
+  if (!d_row_ptr || !d_index || !d_vec || !d_out || (n_long > 0 && (!d_long_rows || !d_workspace)))
+    return fail(OZK_E_INVALID, "null pointer argument");
+  if (rows <= 0 || n_long < 0) return fail(OZK_E_INVALID, "bad row count");
+  if (n_long > 0 && workspace_bytes < ozk_r1cs_evaluate_workspace_bytes(n_long))
+    return fail(OZK_E_INVALID, "workspace too small: need %zu bytes, got %zu", ozk_r1cs_evaluate_workspace_bytes(n_long),
+                workspace_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_r1cs_eval<false>, dim3((rows + 255) / 256), dim3(256), 0, st, (const u32*)d_row_ptr,
+                     (const u32*)d_index, (const u32*)d_coeff, (const u32*)d_vec, rows, (u32*)d_out);
+  if (n_long > 0) {
+    hipLaunchKernelGGL(k_r1cs_eval_long1<false>, dim3(n_long * R1CS_SPLIT), dim3(256), 0, st, (const u32*)d_row_ptr,
+                       (const u32*)d_index, (const u32*)d_coeff, (const u32*)d_vec, (const u32*)d_long_rows,
+                       (u32*)d_workspace);
+    hipLaunchKernelGGL(k_r1cs_eval_long2, dim3(n_long), dim3(256), 0, st, (const u32*)d_long_rows,
+                       (const u32*)d_workspace, (u32*)d_out);
+  }
+  OZK_HIP(hipGetLastError());
+  return OZK_OK;
+}
+
+// Lagrange coefficients of the radix-2 domain of size m at t (FFTAuxiliary.java:250-302) and Z(t) = t^m - 1.
+// d_out: m x 32 B plain LE; d_zt: 32 B; workspace: ozk_qap_lagrange_workspace_bytes(m).  t must not be a domain
+// element (the caller tests t^m == 1 and takes the reference's indicator branch itself: it never happens for a
+// random t).  omega: the domain's root of unity.
+size_t ozk_qap_lagrange_workspace_bytes(int32_t m) {
+  if (m <= 1 || (m & (m - 1))) return 0;
+  const int hi = (m + TW_LO - 1) / TW_LO + 1;
+  return pad256(sizeof(LagConsts)) + pad256((size_t)(TW_LO + hi) * 32) + 512;
+}
+int ozk_qap_lagrange_dev(const uint8_t* t_host32, const uint8_t* omega_host32, int32_t m, void* d_out, void* d_zt,
+                         void* d_workspace, size_t workspace_bytes, void* stream) {
+  if (!t_host32 || !omega_host32 || !d_out || !d_zt || !d_workspace) return fail(OZK_E_INVALID, "null pointer argument");
+  if (m <= 1 || (m & (m - 1)) || m > (1 << 28)) return fail(OZK_E_INVALID, "domain size %d is not a power of two in [2, 2^28]", m);
+  if (workspace_bytes < ozk_qap_lagrange_workspace_bytes(m)) return fail(OZK_E_INVALID, "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  uint8_t* w = (uint8_t*)d_workspace;
+  LagConsts* c = (LagConsts*)w;
+  u32* pw = (u32*)(w + pad256(sizeof(LagConsts)));
+  u32* d_omega = (u32*)(w + pad256(sizeof(LagConsts)) + pad256((size_t)(TW_LO + (m + TW_LO - 1) / TW_LO + 1) * 32));
+  OZK_HIP(hipMemcpyAsync(c->t_wire, t_host32, 32, hipMemcpyHostToDevice, st));
+  OZK_HIP(hipMemcpyAsync(d_omega, omega_host32, 32, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_lag_consts, dim3(1), dim3(64), 0, st, c, m);
+  const int hi = (m + TW_LO - 1) / TW_LO + 1;
+  hipLaunchKernelGGL(k_tw_small, dim3((TW_LO + hi + 255) / 256), dim3(256), 0, st, d_omega, TW_LO, hi, pw);
+  const int lanes = (m + LAG_BATCH - 1) / LAG_BATCH;
+  hipLaunchKernelGGL(k_lagrange, dim3((lanes + 255) / 256), dim3(256), 0, st, c, pw, TW_LO, m, (u32*)d_out);
+  OZK_HIP(hipMemcpyAsync(d_zt, c->z_wire, 32, hipMemcpyDeviceToDevice, st));
+  OZK_HIP(hipGetLastError());
+  return OZK_OK;
+}
+
+// d_out[i] = base^i * k mod r for i < n (32-byte plain LE); base, k: 32-byte LE host values.
+size_t ozk_fr_powers_workspace_bytes(int32_t n) {
+  if (n <= 0) return 0;
+  const int hi = (n + TW_LO - 1) / TW_LO + 1;
+  return pad256((size_t)(TW_LO + hi) * 32) + 512;
+}
+int ozk_fr_powers_dev(const uint8_t* base_host32, const uint8_t* k_host32, int32_t n, void* d_out, void* d_workspace,
+                      size_t workspace_bytes, void* stream) {
+  if (!base_host32 || !k_host32 || !d_out || !d_workspace) return fail(OZK_E_INVALID, "null pointer argument");
+  if (n <= 0 || n > (1 << 28) + 1) return fail(OZK_E_INVALID, "count %d out of range", n);
+  if (workspace_bytes < ozk_fr_powers_workspace_bytes(n)) return fail(OZK_E_INVALID, "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int hi = (n + TW_LO - 1) / TW_LO + 1;
+  u32* pw = (u32*)d_workspace;
+  u32* cst = (u32*)((uint8_t*)d_workspace + pad256((size_t)(TW_LO + hi) * 32));  // [0..8) base, [8..16) k
+  OZK_HIP(hipMemcpyAsync(cst, base_host32, 32, hipMemcpyHostToDevice, st));
+  OZK_HIP(hipMemcpyAsync(cst + 8, k_host32, 32, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_to_mont_inplace, dim3(1), dim3(64), 0, st, cst + 8, 1);
+  hipLaunchKernelGGL(k_tw_small, dim3((TW_LO + hi + 255) / 256), dim3(256), 0, st, cst, TW_LO, hi, pw);
+  hipLaunchKernelGGL(k_powers_scaled, dim3((n + 255) / 256), dim3(256), 0, st, pw, TW_LO, n, cst + 8, (u32*)d_out);
+  OZK_HIP(hipGetLastError());
+  return OZK_OK;
+}
+
+// d_out[i] = (ka a_i + kb b_i + c_i) * kk mod r; a, b, c, out: n x 32 B plain LE in HBM (out may alias an input);
+// ka, kb, kk: 32-byte LE host values; d_scratch: 96 bytes of device memory for the three constants.
+int ozk_fr_lincomb3_dev(const void* d_a, const void* d_b, const void* d_c, int32_t n, const uint8_t* ka_host32,
+                        const uint8_t* kb_host32, const uint8_t* kk_host32, void* d_out, void* d_scratch96, void* stream) {
+  if (!d_a || !d_b || !d_c || !ka_host32 || !kb_host32 || !kk_host32 || !d_out || !d_scratch96)
+    return fail(OZK_E_INVALID, "null pointer argument");
+  if (n <= 0) return fail(OZK_E_INVALID, "count %d out of range", n);
+  hipStream_t st = (hipStream_t)stream;
+  u32* k3 = (u32*)d_scratch96;
+  OZK_HIP(hipMemcpyAsync(k3, ka_host32, 32, hipMemcpyHostToDevice, st));
+  OZK_HIP(hipMemcpyAsync(k3 + 8, kb_host32, 32, hipMemcpyHostToDevice, st));
+  OZK_HIP(hipMemcpyAsync(k3 + 16, kk_host32, 32, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_to_mont_inplace, dim3(1), dim3(64), 0, st, k3, 3);
+  hipLaunchKernelGGL(k_lincomb3, dim3((n + 255) / 256), dim3(256), 0, st, (const u32*)d_a, (const u32*)d_b,
+                     (const u32*)d_c, n, k3, (u32*)d_out);
   OZK_HIP(hipGetLastError());
   return OZK_OK;
 }

@@ -233,7 +233,8 @@ __global__ void __launch_bounds__(256) k_fb_norm(const u32* __restrict__ jac, in
 // per table entry for the normalisation.  Infinity entries (entry 0 of every window; every entry when the
 // base is infinity) become the (0, 0) marker.
 template <class CV>
-__global__ void __launch_bounds__(256) k_fb_table_affine(const u32* __restrict__ jac, int n, u32* __restrict__ aff) {
+__global__ void __launch_bounds__(256) k_fb_table_affine(const u32* __restrict__ jac, int n, u32* __restrict__ aff,
+                                                         u32* __restrict__ aff_phi) {
   using IO = CurveIO<CV>;
   using EA = typename CV::EA;
   using EZ32 = decltype(reduce_to<32>(typename CV::EZ()));
@@ -274,13 +275,23 @@ __global__ void __launch_bounds__(256) k_fb_table_affine(const u32* __restrict__
         q.y = EA(reduce_to<17>(mul(p.Y, mul(zi2, zi))));
       }
       IO::store_aff(q, aff + at(k) * IO::AFF_WORDS);
+      // the same entry under the endomorphism, phi(x, y) = (beta x, y): the second half scalar gathers from this
+      // copy, so both halves add into ONE accumulator (k_fb_main_glv_affine); (0, 0) stays (0, 0)
+      q.x = EA(reduce_to<17>(scale(q.x, glv_beta_fixed<CV>())));
+      IO::store_aff(q, aff_phi + at(k) * IO::AFF_WORDS);
     }
   }
 }
 
+// s B = s2 (s1 s2 (sum_w T[w][d1_w]) + sum_w T_phi[w][d2_w]) with s1, s2 = +-1 the signs of the two half scalars: ONE
+// accumulator takes the 2 ceil(128 / ws) gathers of both halves, negated between the halves when the signs differ
+// and at the end when the second is negative.  (Round 2 kept one accumulator per half and joined them with a
+// general XYZZ addition: for G2 that is two 72-word points live at once — 256 VGPRs, 40 of them spilled, and
+// 720 bytes of scratch per lane; and 17 multiplications per scalar the single accumulator does not need.)
 template <class CV>
 __global__ void __launch_bounds__(256, CV::LDS_ACC ? 2 : 1) k_fb_main_glv_affine(const u32* __restrict__ scalars, const u32* __restrict__ aff,
-                                                            int n, int oc, int ws, u32* __restrict__ jac_out) {
+                                                            const u32* __restrict__ aff_phi, int n, int oc, int ws,
+                                                            u32* __restrict__ jac_out) {
   using IO = CurveIO<CV>;
   using EA = typename CV::EA;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -296,38 +307,36 @@ __global__ void __launch_bounds__(256, CV::LDS_ACC ? 2 : 1) k_fb_main_glv_affine
   Aff<EA> inf;
   inf.x = EA(el_zero(inf.x));
   inf.y = EA(el_zero(inf.x));
-  Xyzz<CV> part[2];
-#pragma unroll
+  // G2: the accumulator lives in LDS (as in the variable-base level 1) — two waves per SIMD instead of one
+  using Acc = std::conditional_t<CV::LDS_ACC, RunAccLds<CV>, RunAcc<CV, true>>;
+  Acc acc;
+  if constexpr (CV::LDS_ACC) {
+    extern __shared__ u32 ozk_acc_lds[];
+    acc.init(ozk_acc_lds);
+  }
+  acc.start_q(inf);
+#pragma unroll 1
   for (int h = 0; h < 2; h++) {
-    const u32* k = h ? k2 : k1;
-    // G2: the accumulator lives in LDS (as in the variable-base level 1) — two waves per SIMD instead of one
-    using Acc = std::conditional_t<CV::LDS_ACC, RunAccLds<CV>, RunAcc<CV, true>>;
-    Acc acc;
-    if constexpr (CV::LDS_ACC) {
-      extern __shared__ u32 ozk_acc_lds[];
-      acc.init(ozk_acc_lds);
-    }
-    acc.start_q(inf);
+    const u32 kk0 = h ? k2[0] : k1[0], kk1 = h ? k2[1] : k1[1], kk2 = h ? k2[2] : k1[2], kk3 = h ? k2[3] : k1[3];
+    const u32* tab = h ? aff_phi : aff;
     for (int w = 0; w < oc; w++) {
       const int bit = w * ws;
       u32 d = 0;
       if (bit < 128) {
         const int wi = bit >> 5, sh = bit & 31;
-        unsigned long long v = k[wi];
-        if (wi + 1 < 4) v |= (unsigned long long)k[wi + 1] << 32;
+        const u32 lo = wi == 0 ? kk0 : wi == 1 ? kk1 : wi == 2 ? kk2 : kk3;
+        const u32 hi = wi == 0 ? kk1 : wi == 1 ? kk2 : wi == 2 ? kk3 : 0u;
+        const unsigned long long v = (unsigned long long)lo | ((unsigned long long)hi << 32);
         d = (u32)(v >> sh) & ((1u << ws) - 1u);
       }
-      if (d != 0) acc.accumulate_q(IO::load_aff(aff + (((size_t)w << ws) + d) * IO::AFF_WORDS));
+      if (d != 0) acc.accumulate_q(IO::load_aff(tab + (((size_t)w << ws) + d) * IO::AFF_WORDS));
     }
-    Xyzz<CV> r;
-    if constexpr (CV::LDS_ACC) r = acc.get();
-    else r = acc.a;
-    if (h ? n2 : n1) r.Y = typename CV::XY(reduce_to<32>(neg(reduce_to<32>(r.Y))));
-    part[h] = r;
+    if (h == 0 ? (n1 != n2) : n2) acc.negate();
   }
-  // phi(x, y) = (beta x, y): X -> beta X in XYZZ as well
-  part[1].X = typename CV::XX(reduce_to<32>(scale(part[1].X, glv_beta_fixed<CV>())));
-  IO::store_jac(xyzz_to_jac(xyzz_add(part[0], part[1])), jac_out + (size_t)i * IO::JAC_WORDS);
+  Xyzz<CV> r;
+  if constexpr (CV::LDS_ACC) r = acc.get();
+  else r = acc.a;
+  IO::store_jac(xyzz_to_jac(r), jac_out + (size_t)i * IO::JAC_WORDS);
 }
 
 // x_i * b mod r, 64-byte big-endian out (field_MSM, FixedBaseMSM.cu:1241-1266)
@@ -341,7 +350,7 @@ __global__ void __launch_bounds__(256) k_field_mul(const u32* __restrict__ in, i
 }
 
 struct FbLayout {
-  u32 *D, *table, *aff, *jac;
+  u32 *D, *table, *aff, *aff_phi, *jac;
   size_t bytes;
 };
 template <class CV>
@@ -351,7 +360,8 @@ static FbLayout fb_layout(int outerc, int ws, int n, void* wsp, size_t wsb) {
   Bump b(wsp, wsb);
   L.D = b.take<u32>((size_t)outerc * ws * IO::JAC_WORDS);
   L.table = b.take<u32>(((size_t)outerc << ws) * IO::JAC_WORDS);
-  L.aff = b.take<u32>(((size_t)outerc << ws) * IO::AFF_WORDS);  // the table again, affine (GLV form)
+  L.aff = b.take<u32>(((size_t)outerc << ws) * IO::AFF_WORDS);  // the table again, affine (GLV form) ...
+  L.aff_phi = b.take<u32>(((size_t)outerc << ws) * IO::AFF_WORDS);  // ... and its image under the endomorphism
   L.jac = b.take<u32>((size_t)n * IO::JAC_WORDS);
   b.take<u32>(64);
   L.bytes = b.off;
@@ -412,7 +422,8 @@ static int fb_table(int outerc, int ws, int n, const void* d_base, void* wsp, si
   if (plan->affine) {
     const int entries = oc << wt;
     const int tl = (entries + FB_BATCH - 1) / FB_BATCH;
-    hipLaunchKernelGGL((k_fb_table_affine<CV>), dim3((tl + TB - 1) / TB), dim3(TB), 0, st, L.table, entries, L.aff);
+    hipLaunchKernelGGL((k_fb_table_affine<CV>), dim3((tl + TB - 1) / TB), dim3(TB), 0, st, L.table, entries, L.aff,
+                       L.aff_phi);
   }
   OZK_HIP(hipGetLastError());
   return OZK_OK;
@@ -432,8 +443,8 @@ static int fb_apply(const FbPlan& fp, int outerc, int ws, int n, int lo, int cnt
     if (acc_lds > 65536)
       OZK_HIP(hipFuncSetAttribute((const void*)(k_fb_main_glv_affine<CV>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)acc_lds));
-    hipLaunchKernelGGL((k_fb_main_glv_affine<CV>), dim3((cnt + TB - 1) / TB), dim3(TB), acc_lds, st, sc, L.aff, cnt,
-                       fp.oc, fp.wt, jac);
+    hipLaunchKernelGGL((k_fb_main_glv_affine<CV>), dim3((cnt + TB - 1) / TB), dim3(TB), acc_lds, st, sc, L.aff,
+                       L.aff_phi, cnt, fp.oc, fp.wt, jac);
   } else if (fp.glv)
     hipLaunchKernelGGL((k_fb_main_glv<CV>), dim3((cnt + TB - 1) / TB), dim3(TB), 0, st, sc, L.table, cnt, fp.oc, fp.wt,
                        jac);

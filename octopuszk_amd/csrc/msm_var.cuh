@@ -777,6 +777,7 @@ struct RunAcc<CV, true> {
   }
   __device__ __forceinline__ void accumulate_signed(const Aff<EA>& q, bool negate) { a = xyzz_madd_lazy(a, q, negate); }
   __device__ __forceinline__ void store(u32* dst) const { IO::store_rec_xyzz(a, dst); }
+  __device__ __forceinline__ void negate() { a.Y = typename CV::XY(reduce_to<32>(neg(reduce_to<32>(a.Y)))); }
   // neutral element in the XYZZ record format (chunk cut on both sides)
   __device__ __forceinline__ void store_infinity(u32* dst) const {
     Xyzz<CV> z = a;
@@ -875,6 +876,9 @@ struct RunAccLds {
     return a;
   }
   __device__ __forceinline__ void store(u32* dst) const { IO::store_rec_xyzz(get(), dst); }
+  __device__ __forceinline__ void negate() const {
+    st(1, typename CV::XY(reduce_to<32>(neg(reduce_to<32>(ld<typename CV::XY>(1))))));
+  }
   __device__ __forceinline__ void store_infinity(u32* dst) const {
     Xyzz<CV> z = get();
     z.ZZ = typename CV::XZZ(el_zero(z.ZZ));

@@ -70,6 +70,12 @@ _SIGS = {
     "ozk_fft_dev": (ctypes.c_int, [vp, i32, vp, vp, vp, sz, vp]),
     "ozk_r1cs_evaluate_workspace_bytes": (sz, [i32]),
     "ozk_r1cs_evaluate_dev": (ctypes.c_int, [vp, vp, vp, vp, i32, vp, i32, vp, vp, sz, vp]),
+    "ozk_qap_lagrange_workspace_bytes": (sz, [i32]),
+    "ozk_qap_lagrange_dev": (ctypes.c_int, [vp, vp, i32, vp, vp, vp, sz, vp]),
+    "ozk_sparse_mat_vec_dev": (ctypes.c_int, [vp, vp, vp, vp, i32, vp, i32, vp, vp, sz, vp]),
+    "ozk_fr_powers_workspace_bytes": (sz, [i32]),
+    "ozk_fr_powers_dev": (ctypes.c_int, [vp, vp, i32, vp, vp, sz, vp]),
+    "ozk_fr_lincomb3_dev": (ctypes.c_int, [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]),
     "ozk_qap_witness_host": (ctypes.c_int, [vp, vp, vp, i32, vp, vp, i32, vp]),
     "ozk_qap_witness_workspace_bytes": (sz, [i32]),
     "ozk_qap_witness_dev": (ctypes.c_int, [vp, vp, vp, i32, vp, vp, vp, vp, sz, vp]),

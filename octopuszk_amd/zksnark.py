@@ -25,6 +25,7 @@ Proof elements are returned in the wire-out format of the variable-base natives 
 64-byte little-endian coordinates).  There is no CPU fallback: without the HIP library nothing here works.
 """
 import ctypes
+import os
 import time
 
 import numpy as np
@@ -322,6 +323,107 @@ def r1cs_to_qap_relation(r1cs: R1CSRelation, t: int) -> QAPRelation:
     return q
 
 
+# ---------------------------------------------------------------------------- QAP instance at t (device)
+def _le32_one(v: int):
+    return ctypes.create_string_buffer(int(v % FR).to_bytes(32, "little"), 32)
+
+
+def _ints_from_dev(t: torch.Tensor):
+    raw = bytes(t.cpu().numpy())
+    return [int.from_bytes(raw[k:k + 32], "little") for k in range(0, len(raw), 32)]
+
+
+class R1CSTransposedDevice:
+    """The constraint matrices TRANSPOSED, resident in HBM as CSR: row j = the terms (constraint i, coefficient) of
+    variable j, with the `input_i * 0 = 0` rows R1CStoQAPRelation adds to A (R1CStoQAP.java:52-55: At[i] gets the
+    Lagrange coefficient of constraint numConstraints + i).  Built once per R1CS on the host (a stable sort of the
+    terms by variable); At / Bt / Ct at any t are then one sparse product each with the Lagrange vector."""
+
+    def __init__(self, r1cs: R1CSRelation):
+        nc, ni, nv = r1cs.num_constraints, r1cs.num_inputs, r1cs.num_variables
+        self.nv = nv
+        self.mats = []
+        for k, lc in enumerate((r1cs.A, r1cs.B, r1cs.C)):
+            rows, cols, val = lc.row_of_term(), lc.index, lc.value
+            if k == 0:
+                rows = np.concatenate((rows, nc + np.arange(ni, dtype=np.int64)))
+                cols = np.concatenate((cols, np.arange(ni, dtype=np.int64)))
+                if val is not None:
+                    val = np.concatenate((val, np.ones(ni, dtype=object)))
+            order = np.argsort(cols, kind="stable")
+            ptr = np.concatenate(([0], np.cumsum(np.bincount(cols, minlength=nv))))
+            idx = rows[order]
+            assert len(ptr) == nv + 1 and ptr[-1] == len(idx) < 1 << 32
+            long_rows = np.nonzero(np.diff(ptr) > 64)[0].astype(np.uint32)
+            self.mats.append(dict(
+                ptr=torch.from_numpy(ptr.astype(np.uint32).view(np.uint8).copy()).cuda(),
+                idx=torch.from_numpy(idx.astype(np.uint32).view(np.uint8).copy()).cuda(),
+                coeff=None if val is None else _dev_bytes(_le32(int(v) % FR for v in val[order])),
+                long=torch.from_numpy(long_rows.view(np.uint8).copy()).cuda() if len(long_rows) else None,
+                n_long=len(long_rows)))
+        self.ws_bytes = int(_lib.load().ozk_r1cs_evaluate_workspace_bytes(max(d["n_long"] for d in self.mats)))
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device="cuda")
+
+
+class QAPRelationDevice:
+    """R1CStoQAP.R1CStoQAPRelation (R1CStoQAP.java:37-98) with At, Bt, Ct, Ht left in HBM (n x 32-byte LE values);
+    the integer lists the host version offers (At, Bt, Ct, Ht) are downloaded on first use (tests)."""
+
+    def __init__(self):
+        self._cache = {}
+
+    def _ints(self, name):
+        if name not in self._cache:
+            self._cache[name] = _ints_from_dev(getattr(self, "d_" + name))
+        return self._cache[name]
+
+    At = property(lambda self: self._ints("At"))
+    Bt = property(lambda self: self._ints("Bt"))
+    Ct = property(lambda self: self._ints("Ct"))
+    Ht = property(lambda self: self._ints("Ht"))
+
+
+def r1cs_to_qap_relation_dev(r1cs: R1CSRelation, t: int, transposed: R1CSTransposedDevice = None) -> QAPRelationDevice:
+    """The QAP instance at t on the device: Lagrange coefficients (ozk_qap_lagrange_dev, FFTAuxiliary.java:250-302),
+    three sparse products over the transposed matrices (ozk_sparse_mat_vec_dev), the powers of t
+    (ozk_fr_powers_dev).  Falls back to the host version when t lies in the domain (t^m = 1: the reference's
+    indicator branch, FFTAuxiliary.java:272-283; probability m / r for a random t)."""
+    L = _lib.load()
+    nc, ni, nv = r1cs.num_constraints, r1cs.num_inputs, r1cs.num_variables
+    m = lowest_power_of_two(nc + ni)
+    if m < 2 or pow(t, m, FR) == 1:
+        return r1cs_to_qap_relation(r1cs, t)
+    T = transposed if transposed is not None else R1CSTransposedDevice(r1cs)
+    q = QAPRelationDevice()
+    st = _stream()
+    d_lag = torch.empty(m * 32, dtype=torch.uint8, device="cuda")
+    d_zt = torch.empty(32, dtype=torch.uint8, device="cuda")
+    wsb = int(L.ozk_qap_lagrange_workspace_bytes(m))
+    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    tb, ob = _le32_one(t), _le32_one(root_of_unity(m))
+    _lib.check(L.ozk_qap_lagrange_dev(ctypes.cast(tb, ctypes.c_void_p), ctypes.cast(ob, ctypes.c_void_p), m, _ptr(d_lag),
+                                      _ptr(d_zt), _ptr(ws), wsb, st))
+    outs = []
+    for d in T.mats:
+        out = torch.empty(nv * 32, dtype=torch.uint8, device="cuda")
+        _lib.check(L.ozk_sparse_mat_vec_dev(_ptr(d["ptr"]), _ptr(d["idx"]), _ptr(d["coeff"]) if d["coeff"] is not None else None,
+                                            _ptr(d_lag), nv, _ptr(d["long"]) if d["long"] is not None else None,
+                                            d["n_long"], _ptr(out), _ptr(T.ws), T.ws_bytes, st))
+        outs.append(out)
+    q.d_At, q.d_Bt, q.d_Ct = outs
+    q.d_Ht = torch.empty((m + 1) * 32, dtype=torch.uint8, device="cuda")
+    pwb = int(L.ozk_fr_powers_workspace_bytes(m + 1))
+    pws = torch.empty(pwb, dtype=torch.uint8, device="cuda")
+    one = _le32_one(1)
+    _lib.check(L.ozk_fr_powers_dev(ctypes.cast(tb, ctypes.c_void_p), ctypes.cast(one, ctypes.c_void_p), m + 1, _ptr(q.d_Ht),
+                                   _ptr(pws), pwb, st))
+    torch.cuda.current_stream().synchronize()       # the host buffers and workspaces above die here
+    q.Zt = int.from_bytes(bytes(d_zt.cpu().numpy()), "little")
+    q.d_lagrange = d_lag
+    q.t, q.num_inputs, q.num_variables, q.degree = t, ni, nv, m
+    return q
+
+
 # ---------------------------------------------------------------------------- fixed-base batches on the device
 def _num_windows(scalar_size, window_size):
     return scalar_size // window_size if scalar_size % window_size == 0 else scalar_size // window_size + 1
@@ -331,12 +433,13 @@ def batch_msm_dev(scalar_size: int, window_size: int, base_wire: bytes, scalars,
     """FixedBaseMSM.batchMSM (FixedBaseMSM.java:186-315) with the result left in HBM in the variable-base
     wire-in format: uint8 tensor n x 96 (G1) / n x 192 (G2)."""
     L = _lib.load()
-    n = len(scalars)
+    on_device = isinstance(scalars, torch.Tensor)   # n x 32-byte LE values already in HBM, or a list of ints
+    n = scalars.numel() // 32 if on_device else len(scalars)
     outerc = (scalar_size + window_size - 1) // window_size   # FixedBaseMSM.java:212
     if outerc * window_size < 254:
         raise _lib.OzkError("window plan covers %d bits of a 254-bit scalar" % (outerc * window_size))
     d_base = _dev_bytes(base_wire)
-    d_sc = _dev_bytes(_le32(scalars))
+    d_sc = scalars if on_device else _dev_bytes(_le32(scalars))
     out = torch.empty(n * (96 if type_ == 1 else 192), dtype=torch.uint8, device="cuda")
     wsb = int(L.ozk_fixed_batch_msm_workspace_bytes(outerc, window_size, n, type_))
     ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
@@ -349,6 +452,17 @@ def batch_msm_dev(scalar_size: int, window_size: int, base_wire: bytes, scalars,
 def _bit_size(wire: bytes) -> int:
     """BNG1.bitSize / BNG2.bitSize (BNG1.java:174-176): the longest coordinate."""
     return max(int.from_bytes(wire[k:k + 32], "little").bit_length() for k in range(0, len(wire), 32))
+
+
+class _LazyScalars(dict):
+    """the scalars behind the key elements, as lists of ints; device-resident ones are downloaded on first use"""
+
+    def __getitem__(self, k):
+        v = dict.__getitem__(self, k)
+        if isinstance(v, torch.Tensor):
+            v = _ints_from_dev(v)
+            dict.__setitem__(self, k, v)
+        return v
 
 
 class ProvingKey:
@@ -366,14 +480,46 @@ def serial_setup_generate(r1cs: R1CSRelation, seed: int = SEED, log=None) -> CRS
     t0 = time.perf_counter()
     t = alpha = beta = gamma = delta = fr_random(seed)          # :40-44
     inv_gamma, inv_delta = pow(gamma, -1, FR), pow(delta, -1, FR)
-    qap = r1cs_to_qap_relation(r1cs, t)                         # :50
-    tm["qap_relation_host_s"] = time.perf_counter() - t0
+    on_device = os.environ.get("OZK_SETUP_HOST", "0") != "1"
+    if on_device:
+        # the transposed matrices are a property of the R1CS (built once, like the CSR arrays of R1CSDevice), not of t
+        if getattr(r1cs, "_transposed_dev", None) is None:
+            r1cs._transposed_dev = R1CSTransposedDevice(r1cs)
+            torch.cuda.synchronize()
+        tm["r1cs_transpose_once_host_s"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        qap = r1cs_to_qap_relation_dev(r1cs, t, r1cs._transposed_dev)                          # :50
+    else:
+        qap = r1cs_to_qap_relation(r1cs, t)
+    on_device = isinstance(qap, QAPRelationDevice)
+    if on_device:
+        torch.cuda.synchronize()
+    tm["qap_relation_%s_s" % ("device" if on_device else "host")] = time.perf_counter() - t0
     ni, nv = qap.num_inputs, qap.num_variables
-    abc = [(beta * a + alpha * b + c) % FR for a, b, c in zip(qap.At, qap.Bt, qap.Ct)]
-    gamma_abc = [x * inv_gamma % FR for x in abc[:ni]]          # :61-66
-    delta_abc = [x * inv_delta % FR for x in abc[ni:]]          # :69-74
-    non_zero_at = sum(1 for x in qap.At if x)                   # :76-88
-    non_zero_bt = sum(1 for x in qap.Bt if x)
+    if on_device:
+        # (beta At + alpha Bt + Ct) / gamma for the inputs, / delta for the rest (:61-74), and the non-zero counts
+        # behind the window sizes (:76-88), without the values leaving HBM
+        L = _lib.load()
+        k3 = torch.empty(96, dtype=torch.uint8, device="cuda")
+        d_gamma_abc = torch.empty(ni * 32, dtype=torch.uint8, device="cuda")
+        d_delta_abc = torch.empty((nv - ni) * 32, dtype=torch.uint8, device="cuda")
+        kb, ka = _le32_one(beta), _le32_one(alpha)
+        for lo, cnt, kk, out in ((0, ni, inv_gamma, d_gamma_abc), (ni, nv - ni, inv_delta, d_delta_abc)):
+            if cnt > 0:
+                kkb = _le32_one(kk)
+                _lib.check(L.ozk_fr_lincomb3_dev(_ptr(qap.d_At) + 32 * lo, _ptr(qap.d_Bt) + 32 * lo, _ptr(qap.d_Ct) + 32 * lo,
+                                                 cnt, ctypes.cast(kb, ctypes.c_void_p), ctypes.cast(ka, ctypes.c_void_p),
+                                                 ctypes.cast(kkb, ctypes.c_void_p), _ptr(out), _ptr(k3), _stream()))
+                torch.cuda.current_stream().synchronize()
+        gamma_abc, delta_abc = d_gamma_abc, d_delta_abc
+        non_zero_at = int((qap.d_At.view(nv, 32) != 0).any(dim=1).sum().item())
+        non_zero_bt = int((qap.d_Bt.view(nv, 32) != 0).any(dim=1).sum().item())
+    else:
+        abc = [(beta * a + alpha * b + c) % FR for a, b, c in zip(qap.At, qap.Bt, qap.Ct)]
+        gamma_abc = [x * inv_gamma % FR for x in abc[:ni]]          # :61-66
+        delta_abc = [x * inv_delta % FR for x in abc[ni:]]          # :69-74
+        non_zero_at = sum(1 for x in qap.At if x)                   # :76-88
+        non_zero_bt = sum(1 for x in qap.Bt if x)
     # :91-112 generators = one * random, window sizes from the per-curve tables
     rnd = fr_random(seed)
     gen_g1 = bytes(batch_msm_dev(254, 16, g1_wire(G1_ONE), [rnd], 1).cpu().numpy())
@@ -395,11 +541,21 @@ def serial_setup_generate(r1cs: R1CSRelation, seed: int = SEED, log=None) -> CRS
     k2 = b2([beta, delta, gamma])
     pk.beta_g2, pk.delta_g2, gamma_g2 = k2[:192], k2[192:384], k2[384:576]
     pk.delta_abc_g1 = b1(delta_abc)                             # :123-126
-    pk.query_a = b1(qap.At)                                     # :128-131
-    pk.query_b_g1 = b1(qap.Bt)                                  # :133-144 doubleBatchMSM: G1 and G2 over Bt
-    pk.query_b_g2 = b2(qap.Bt)
+    pk.query_a = b1(qap.d_At if on_device else qap.At)          # :128-131
+    pk.query_b_g1 = b1(qap.d_Bt if on_device else qap.Bt)       # :133-144 doubleBatchMSM: G1 and G2 over Bt
+    pk.query_b_g2 = b2(qap.d_Bt if on_device else qap.Bt)
     inv_delta_zt = qap.Zt * inv_delta % FR                      # :146-151
-    ht_scalars = [h * inv_delta_zt % FR for h in qap.Ht]
+    if on_device:
+        L = _lib.load()
+        ht_scalars = torch.empty((qap.degree + 1) * 32, dtype=torch.uint8, device="cuda")
+        pwb = int(L.ozk_fr_powers_workspace_bytes(qap.degree + 1))
+        pws = torch.empty(pwb, dtype=torch.uint8, device="cuda")
+        tb, kb2 = _le32_one(t), _le32_one(inv_delta_zt)
+        _lib.check(L.ozk_fr_powers_dev(ctypes.cast(tb, ctypes.c_void_p), ctypes.cast(kb2, ctypes.c_void_p), qap.degree + 1,
+                                       _ptr(ht_scalars), _ptr(pws), pwb, _stream()))
+        torch.cuda.current_stream().synchronize()
+    else:
+        ht_scalars = [h * inv_delta_zt % FR for h in qap.Ht]
     pk.query_h = b1(ht_scalars)
     pk.r1cs = r1cs
     crs = CRS()
@@ -410,14 +566,15 @@ def serial_setup_generate(r1cs: R1CSRelation, seed: int = SEED, log=None) -> CRS
     # kept for checks in the exponent (tests): the scalars behind every key element
     crs.qap = qap
     crs.secrets = dict(t=t, alpha=alpha, beta=beta, gamma=gamma, delta=delta, generator=rnd)
-    crs.scalars = dict(delta_abc=delta_abc, gamma_abc=gamma_abc, ht=ht_scalars)
+    crs.scalars = _LazyScalars(delta_abc=delta_abc, gamma_abc=gamma_abc, ht=ht_scalars)
     crs.gen_g1, crs.gen_g2 = gen_g1, gen_g2
     crs.window_g1, crs.window_g2 = window_g1, window_g2
     crs.scalar_size_g1, crs.scalar_size_g2 = scalar_size_g1, scalar_size_g2
     crs.timing = tm
     if log:
-        log("setup: QAP instance (host) %.2f s, fixed-base batches (GPU, incl. marshalling) %.2f s"
-            % (tm["qap_relation_host_s"], tm["fixed_base_gpu_s"]))
+        log("setup: QAP instance (%s) %.3f s, fixed-base batches (GPU, incl. marshalling) %.2f s"
+            % ("device" if on_device else "host", tm.get("qap_relation_device_s", tm.get("qap_relation_host_s")),
+               tm["fixed_base_gpu_s"]))
     return crs
 
 

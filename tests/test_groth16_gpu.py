@@ -143,3 +143,39 @@ def test_r1cs_evaluate_with_coefficients_and_long_rows():
     assert got[:rows * 32] == z._le32(oracle_rows) and not any(got[rows * 32:])
     got_a = bytes(ev[0].cpu().numpy())        # A: row `rows` is the extra input_0 * 0 = 0 row, i.e. z_0 = 1
     assert got_a[:rows * 32] == z._le32(oracle_rows) and got_a[rows * 32:(rows + 1) * 32] == z._le32([1])
+
+
+@pytest.mark.parametrize("shape", ["synthetic", "random_coefficients"])
+def test_qap_instance_on_device_equals_host_and_oracle(shape):
+    """R1CStoQAP.R1CStoQAPRelation on the device (Lagrange coefficients with shared inversions, sparse products over
+    the transposed matrices, powers of t) against the host version in exact integers and the oracle's restatement:
+    At, Bt, Ct, Ht, Zt."""
+    import numpy as np
+    from octopuszk_amd import zksnark as z
+    rng = np.random.default_rng(11)
+    if shape == "synthetic":
+        r1cs, _, _ = z.serial_construct(700, 13)
+    else:
+        nv, rows, ni = 500, 300, 7
+        mats = []
+        for _ in range(3):
+            lens = rng.integers(0, 5, size=rows)
+            lens[4], lens[9] = 450, 66                       # long rows; variable columns get long too (below)
+            ptr = np.concatenate(([0], np.cumsum(lens)))
+            idx = rng.integers(0, nv, size=int(ptr[-1]))
+            idx[ptr[4]:ptr[4] + 200] = 3                     # 200 terms of one variable: a long transposed row
+            val = np.array([int.from_bytes(rng.bytes(32), "little") % o.R for _ in range(int(ptr[-1]))], dtype=object)
+            mats.append(z.LinearCombinations(ptr, idx, val))
+        r1cs = z.R1CSRelation(mats[0], mats[1], mats[2], ni, nv - ni)
+    t = z.fr_random()
+    host = z.r1cs_to_qap_relation(r1cs, t)
+    dev = z.r1cs_to_qap_relation_dev(r1cs, t)
+    assert isinstance(dev, z.QAPRelationDevice)
+    assert dev.degree == host.degree and dev.Zt == host.Zt
+    assert dev.At == host.At and dev.Bt == host.Bt and dev.Ct == host.Ct and dev.Ht == host.Ht
+    lag = z._ints_from_dev(dev.d_lagrange)
+    assert lag == z.lagrange_coefficients(t, host.degree) == g.lagrange_coefficients(t, host.degree)
+    # a point of the domain takes the reference's indicator branch (host)
+    w = z.root_of_unity(host.degree)
+    ind = z.r1cs_to_qap_relation_dev(r1cs, pow(w, 5, o.R))
+    assert not isinstance(ind, z.QAPRelationDevice) and ind.Zt == 0

@@ -44,7 +44,7 @@ def main():
     prover.close()
     best = min(rows, key=lambda r: r["gpu_ms"])
     out = {"workload": "serial Groth16 prove, synthetic R1CS 2^%d constraints, %d inputs, domain 2^%d" % (logn, ni, logn + 1),
-           "construct_r1cs_host_s": round(t_construct, 2), "setup": {k: round(v, 2) for k, v in crs.timing.items()},
+           "construct_r1cs_host_s": round(t_construct, 2), "setup": {k: round(v, 4) for k, v in crs.timing.items()},
            "prepare_key_s": round(t_prepare, 3), "marshal_witness_once_s": round(t_marshal, 3), "reps": reps,
            "prove_ms_best": {k: round(v, 2) for k, v in best.items()},
            "prove_gpu_ms_all": [round(r["gpu_ms"], 2) for r in rows]}
