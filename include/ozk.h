@@ -57,6 +57,12 @@ int ozk_tuning_reload(void);
  * pool between calls (the reference allocates and frees inside every native call,
  * algebra_msm_VariableBaseMSM.cu:1292-1303,1405-1409).  This gives everything back. */
 int ozk_host_cache_release(void);
+/* Where the wall time of the calling thread's last `*_host` call went: stats10 = {context acquire, arena growth,
+ * waits for a pinned staging buffer, host memcpy into the ring, host memcpy out of it, enqueueing copies,
+ * stream synchronisation} in milliseconds, the number of staging waits and of host memcpys, and the call's total
+ * time as the library saw it (entry to context release).  (How a call that takes several times its median is
+ * attributed — to one of the library's waits, or to the caller's side of the boundary — tools/host_jitter.py.) */
+int ozk_host_call_stats(double* stats10);
 
 /* ---------------- VariableBaseMSM ---------------------------------------
  * replaces Java_algebra_msm_VariableBaseMSM_variableBaseSerialMSMNativeHelper

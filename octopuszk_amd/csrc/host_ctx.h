@@ -15,6 +15,8 @@
 //     (digit extraction, base conversion) overlapping the rest of the upload.
 // Nothing here computes; ozk_host_cache_release() gives everything back.
 #pragma once
+#include <chrono>
+
 #include "ozk_common.h"
 
 namespace ozk {
@@ -55,15 +57,38 @@ int staged_d2h(HostCtx* c, void* h_dst, const void* d_src, size_t bytes, hipStre
 int staged_d2h_gated(HostCtx* c, void* h_dst, const void* d_src, size_t bytes, hipStream_t st,
                      int (*gate)(void*, size_t), void* gate_arg);
 
+// Where the wall time of the calling thread's current / last `*_host` call went (milliseconds; reset by
+// ctx_acquire).  A call that takes 5x its median has to show up in exactly one of these waits — how the 10-38 ms
+// calls of round 2 were attributed; read with ozk_host_call_stats().
+struct HostCallStats {
+  double acquire_ms = 0, reserve_ms = 0, stage_wait_ms = 0, memcpy_in_ms = 0, memcpy_out_ms = 0, enqueue_ms = 0,
+         sync_ms = 0;
+  int stage_waits = 0, memcpys = 0;
+  double total_ms = 0;  // from the start of ctx_acquire to the release of the context, as the library sees it
+  std::chrono::steady_clock::time_point t_begin;
+};
+HostCallStats& host_call_stats();
+struct StatTimer {   // adds the scope's wall time to a field of the calling thread's stats
+  double& field;
+  std::chrono::steady_clock::time_point t0;
+  explicit StatTimer(double& f) : field(f), t0(std::chrono::steady_clock::now()) {}
+  ~StatTimer() { field += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
 struct CtxGuard {  // release on scope exit
   HostCtx* c = nullptr;
   ~CtxGuard() {
     if (!c) return;
     // an entry point that fails half way may leave work queued that still uses the arena or the staging ring:
     // nothing of a context is handed to the next caller before its streams have drained (idle streams: ~us)
-    for (auto& s : c->st)
-      if (s) hipStreamSynchronize(s);
+    {
+      StatTimer tm(host_call_stats().sync_ms);
+      for (auto& s : c->st)
+        if (s) hipStreamSynchronize(s);
+    }
     ctx_release(c);
+    HostCallStats& hs = host_call_stats();
+    hs.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - hs.t_begin).count();
   }
 };
 

@@ -149,7 +149,15 @@ void ctx_destroy(HostCtx* c) {
 }
 }  // namespace
 
+HostCallStats& host_call_stats() {
+  static thread_local HostCallStats s;
+  return s;
+}
+
 int ctx_acquire(int task_id, HostCtx** out) {
+  host_call_stats() = HostCallStats();
+  host_call_stats().t_begin = std::chrono::steady_clock::now();
+  StatTimer tm(host_call_stats().acquire_ms);
   int rc = select_device(task_id);
   if (rc) return rc;
   int dev = 0;
@@ -194,6 +202,7 @@ void ctx_release(HostCtx* c) {
 
 int ctx_reserve(HostCtx* c, size_t bytes) {
   if (bytes <= c->arena_cap) return OZK_OK;
+  StatTimer tm(host_call_stats().reserve_ms);
   // everything queued on this context's streams may still use the old arena
   for (auto& s : c->st) OZK_HIP(hipStreamSynchronize(s));
   if (c->arena) OZK_HIP(hipFree(c->arena));
@@ -208,6 +217,8 @@ int ctx_reserve(HostCtx* c, size_t bytes) {
 
 static int stage_wait(HostCtx* c, int b) {
   if (c->stage_busy[b]) {
+    StatTimer tm(host_call_stats().stage_wait_ms);
+    host_call_stats().stage_waits++;
     OZK_HIP(hipEventSynchronize(c->stage_free[b]));
     c->stage_busy[b] = false;
   }
@@ -222,7 +233,12 @@ int staged_h2d(HostCtx* c, void* d_dst, const void* h_src, size_t bytes, hipStre
     c->stage_next = (b + 1) % STAGE_RING;
     int rc = stage_wait(c, b);
     if (rc) return rc;
-    parallel_memcpy(c->stage[b], (const uint8_t*)h_src + off, len);
+    {
+      StatTimer tm(host_call_stats().memcpy_in_ms);
+      host_call_stats().memcpys++;
+      parallel_memcpy(c->stage[b], (const uint8_t*)h_src + off, len);
+    }
+    StatTimer tq(host_call_stats().enqueue_ms);
     OZK_HIP(hipMemcpyAsync((uint8_t*)d_dst + off, c->stage[b], len, hipMemcpyHostToDevice, st));
     OZK_HIP(hipEventRecord(c->stage_free[b], st));
     c->stage_busy[b] = true;
@@ -242,6 +258,7 @@ int staged_d2h_gated(HostCtx* c, void* h_dst, const void* d_src, size_t bytes, h
       int rc = gate(gate_arg, bytes);
       if (rc) return rc;
     }
+    StatTimer tm(host_call_stats().sync_ms);
     OZK_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, st));
     OZK_HIP(hipStreamSynchronize(st));
     return OZK_OK;
@@ -259,8 +276,11 @@ int staged_d2h_gated(HostCtx* c, void* h_dst, const void* d_src, size_t bytes, h
       rc = gate(gate_arg, off + len);
       if (rc) return rc;
     }
-    OZK_HIP(hipMemcpyAsync(c->stage[b], (const uint8_t*)d_src + off, len, hipMemcpyDeviceToHost, st));
-    OZK_HIP(hipEventRecord(c->stage_free[b], st));
+    {
+      StatTimer tq(host_call_stats().enqueue_ms);
+      OZK_HIP(hipMemcpyAsync(c->stage[b], (const uint8_t*)d_src + off, len, hipMemcpyDeviceToHost, st));
+      OZK_HIP(hipEventRecord(c->stage_free[b], st));
+    }
     c->stage_busy[b] = true;
     buf_of[k % STAGE_RING] = b;
     return OZK_OK;
@@ -276,7 +296,11 @@ int staged_d2h_gated(HostCtx* c, void* h_dst, const void* d_src, size_t bytes, h
     if (rc) return rc;
     const size_t off = k * STAGE_BYTES;
     const size_t len = (bytes - off < STAGE_BYTES) ? (bytes - off) : STAGE_BYTES;
-    parallel_memcpy((uint8_t*)h_dst + off, c->stage[b], len);
+    {
+      StatTimer tm(host_call_stats().memcpy_out_ms);
+      host_call_stats().memcpys++;
+      parallel_memcpy((uint8_t*)h_dst + off, c->stage[b], len);
+    }
     if (issued < nchunks) {
       rc = issue(issued++);
       if (rc) return rc;
@@ -294,6 +318,24 @@ void fft_plan_cache_release();   // fft.hip
 namespace {
 __attribute__((destructor)) void ozk_host_ctx_unload() { ozk::copy_shutdown(); }
 }  // namespace
+
+// stats10 = {acquire, reserve, stage_wait, memcpy_in, memcpy_out, enqueue, sync (ms), stage waits, memcpys, total ms
+// inside the library} of the calling thread's last *_host call
+extern "C" int ozk_host_call_stats(double* stats9) {
+  if (!stats9) return ozk::fail(OZK_E_INVALID, "null pointer argument");
+  stats9[9] = ozk::host_call_stats().total_ms;
+  const ozk::HostCallStats& s = ozk::host_call_stats();
+  stats9[0] = s.acquire_ms;
+  stats9[1] = s.reserve_ms;
+  stats9[2] = s.stage_wait_ms;
+  stats9[3] = s.memcpy_in_ms;
+  stats9[4] = s.memcpy_out_ms;
+  stats9[5] = s.enqueue_ms;
+  stats9[6] = s.sync_ms;
+  stats9[7] = s.stage_waits;
+  stats9[8] = s.memcpys;
+  return OZK_OK;
+}
 
 extern "C" int ozk_host_cache_release(void) {
   using namespace ozk;

@@ -64,6 +64,7 @@ _SIGS = {
     "ozk_fft_compact_dev": (ctypes.c_int, [vp, i32, vp, vp, vp, sz, vp]),
     "ozk_tuning_reload": (ctypes.c_int, []),
     "ozk_host_cache_release": (ctypes.c_int, []),
+    "ozk_host_call_stats": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double)]),
     "ozk_bases_type": (ctypes.c_int, [vp]),
     "ozk_fft_host": (ctypes.c_int, [vp, i32, vp, i32, vp]),
     "ozk_fft_workspace_bytes": (sz, [i32]),
