@@ -277,14 +277,24 @@ def main():
         ev_stats, ev_launches, ev_ms_per_step = [float(x) for x in es], el.value, (e1 - e0) / args.steps * 1e3
         if bytes(res_ev.cpu().numpy()) != result_bytes:
             raise SystemExit("bench: the HIP-event pass returned a different point")
-    # latency of ONE MSM with nothing else in flight (not part of `value`)
+    # latency of ONE MSM with nothing else in flight (not part of `value`), and the level-1 kernel's duration in that
+    # situation: inside the timed schedule the kernel shares the vector ALU with the next MSM's sort and the previous
+    # MSMs' tails, so its duration there says how the chip was shared, its duration alone what the kernel costs
     lat = []
-    for _ in range(0 if args.timed_only else 5):
-        torch.cuda.synchronize()
-        l0 = time.perf_counter()
-        run_steps(1)
-        torch.cuda.synchronize()
-        lat.append(time.perf_counter() - l0)
+    alone = None
+    if not args.timed_only:
+        ozk.check(L.ozk_prof_enable(2))
+        for _ in range(5):
+            torch.cuda.synchronize()
+            l0 = time.perf_counter()
+            run_steps(1)
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - l0)
+        a4, al = (ctypes.c_double * 4)(), ctypes.c_int()
+        ozk.check(L.ozk_prof_dominant_kernel_stats(a4, ctypes.byref(al)))
+        ozk.check(L.ozk_prof_enable(0))
+        alone = {"mean": round(a4[0], 4), "median": round(a4[1], 4), "min": round(a4[2], 4), "max": round(a4[3], 4),
+                 "launches": al.value, "source": "device clock, five lone MSMs after the timed region"}
     single_ms = sorted(lat)[len(lat) // 2] * 1e3 if lat else 0.0
     # Secondary figure (never `value`): the same MSMs issued as three free-running streams — how concurrent
     # prover threads drive the library.  Higher throughput (everything but the bucket accumulation of one MSM runs
@@ -344,6 +354,7 @@ def main():
                         "ms_per_step_of_that_pass": round(ev_ms_per_step, 4),
                         "source": "HIP start/stop events on the dispatch, second pass of the same steps (an event-carrying "
                                   "dispatch slows the three-stage schedule, hence not inside the timed region)"},
+                    "kernel_ms_alone": alone,
                     "sclk_mhz": sclk_mhz(),
                     "algorithmic_bytes_per_launch": alg_bytes,
                     # the bound that actually holds: v_mad_u64_u32 issue.  10 Montgomery
@@ -355,6 +366,11 @@ def main():
                             "frac": round(10.0 * adds / (k_ms * 1e-3) / 1e9 / 179.0, 3) if k_ms > 0 else 0.0},
                     "note": "integer-ALU-bound: 10 Fq mulmod per XYZZ mixed add x %d points x %d windows%s; see DESIGN.md"
                             % (n * (2 if glv else 1), wn.value, " (GLV: 2n half-length scalars)" if glv else "")}
+        if alone and alone["median"] > 0:
+            # the same ratio for the kernel running alone: what the kernel itself reaches of the multiplier's rate
+            ach = 10.0 * adds / (alone["median"] * 1e-3) / 1e9
+            roofline["alu_alone"] = {"achieved": round(ach, 1), "peak": 179.0, "unit": "G mulmod/s", "frac": round(ach / 179.0, 3)}
+            roofline["frac_alone"] = round(alg_bytes / (alone["median"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             from oracle import coracle  # checker / baseline only

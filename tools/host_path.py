@@ -16,6 +16,11 @@ from octopuszk_amd import device as dev  # noqa: E402
 from octopuszk_amd import lib as ozk  # noqa: E402
 from oracle import bn254 as o  # noqa: E402
 
+# the Python collector's pauses land inside whichever call happens to be timed (10-40 ms, tools/host_jitter.py:
+# the library itself never showed them); they are the harness's, not the entry point's
+import gc  # noqa: E402
+gc.disable()
+
 L = ozk.load()
 
 
