@@ -138,6 +138,14 @@ int ozk_var_msm_head_ordered_dev(const void* d_bases, const void* d_scalars, int
                                  void* stream, void* previous_levels_done);
 int ozk_var_msm_tail_ordered_dev(int32_t n, int32_t type, void* d_tail, size_t tail_bytes, void* d_out, void* stream,
                                  void* levels_done);
+/* The tail's window sums come in two shapes (csrc/msm_var_driver.cuh, tail_shape): LATENCY (mode 0: fused first
+ * level + wave-cooperative levels, the fewest dependent additions; what ozk_var_msm_dev, the host entry points and
+ * the ordered tail above use) and THROUGHPUT (mode 1: serial levels, 3.0 instead of 5.25 additions per bucket,
+ * ~40 dependent additions longer; what ozk_var_msm_tail_dev uses).  A caller that keeps the chip busy with other
+ * work — a prover with five MSMs and a witness map in flight — picks throughput: every addition saved is vector-ALU
+ * time for something else (a 2^20-constraint proof: 16.6 -> 16.3 ms).  levels_done may be NULL. */
+int ozk_var_msm_tail_mode_dev(int32_t n, int32_t type, void* d_tail, size_t tail_bytes, void* d_out, void* stream,
+                              void* levels_done, int32_t mode);
 
 /* The head itself has two stages that stress different units — SORT (base conversion, digits,
  * counting sort: HBM / LDS) and ACCUMULATE (bucket accumulation ... first window-sum level:

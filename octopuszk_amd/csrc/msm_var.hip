@@ -226,6 +226,17 @@ int ozk_var_msm_tail_ordered_dev(int32_t n, int32_t type, void* d_tail, size_t t
     return var_msm_tail<G1Cfg>(n, d_tail, tail_bytes, d_out, (hipStream_t)stream, (hipEvent_t)levels_done);
   return var_msm_tail<G2Cfg>(n, d_tail, tail_bytes, d_out, (hipStream_t)stream, (hipEvent_t)levels_done);
 }
+// the tail with the shape of its window sums chosen by the caller: mode 0 = latency (a lone MSM), 1 = throughput
+// (the caller keeps the chip busy with other work: a prover with five MSMs and a witness map in flight)
+int ozk_var_msm_tail_mode_dev(int32_t n, int32_t type, void* d_tail, size_t tail_bytes, void* d_out, void* stream,
+                              void* levels_done, int32_t mode) {
+  if (!d_tail || !d_out) return fail(OZK_E_INVALID, "null pointer argument");
+  if (n <= 0 || n > (1 << 24)) return fail(OZK_E_INVALID, "batch_size %d out of range [1, 2^24]", n);
+  const int m = mode ? TAIL_THROUGHPUT : TAIL_LATENCY;
+  if (type == OZK_G1)
+    return var_msm_tail<G1Cfg>(n, d_tail, tail_bytes, d_out, (hipStream_t)stream, (hipEvent_t)levels_done, m);
+  return var_msm_tail<G2Cfg>(n, d_tail, tail_bytes, d_out, (hipStream_t)stream, (hipEvent_t)levels_done, m);
+}
 int ozk_var_msm_stage_bytes(int32_t n, int32_t type, size_t* sorted_bytes, size_t* sort_ws_bytes,
                             size_t* accum_ws_bytes) {
   if (n <= 0 || n > (1 << 24) || !sorted_bytes || !sort_ws_bytes || !accum_ws_bytes)

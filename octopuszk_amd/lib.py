@@ -51,6 +51,7 @@ _SIGS = {
     "ozk_order_event_destroy": (ctypes.c_int, [vp]),
     "ozk_var_msm_head_ordered_dev": (ctypes.c_int, [vp, vp, i32, i32, vp, sz, vp, sz, vp, vp]),
     "ozk_var_msm_tail_ordered_dev": (ctypes.c_int, [i32, i32, vp, sz, vp, vp, vp]),
+    "ozk_var_msm_tail_mode_dev": (ctypes.c_int, [i32, i32, vp, sz, vp, vp, vp, i32]),
     "ozk_points_sum_dev": (ctypes.c_int, [vp, i32, i32, vp, vp]),
     "ozk_fixed_batch_msm_host": (ctypes.c_int, [i32, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp]),
     "ozk_fixed_double_batch_msm_host": (ctypes.c_int, [i32] * 9 + [vp, vp, vp, i32, vp]),

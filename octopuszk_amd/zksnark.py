@@ -613,8 +613,10 @@ class _G1Pipeline:
                                                    _ptr(self.tails[slot]), self.tail_bytes, int(main.cuda_stream), prev))
         self.head_done[slot].record(main)
         self.side.wait_event(self.head_done[slot])
-        _lib.check(L.ozk_var_msm_tail_ordered_dev(n, 1, _ptr(self.tails[slot]), self.tail_bytes, _ptr(out),
-                                                  int(self.side.cuda_stream), self.levels_done[slot]))
+        # throughput shape of the window sums: the proof keeps the vector ALU busy from start to end, so the additions
+        # the serial levels save are worth more than the dependent additions they add (include/ozk.h)
+        _lib.check(L.ozk_var_msm_tail_mode_dev(n, 1, _ptr(self.tails[slot]), self.tail_bytes, _ptr(out),
+                                               int(self.side.cuda_stream), self.levels_done[slot], 1))
         self.tail_done[slot].record(self.side)
         self.count += 1
         return self.tail_done[slot]
@@ -667,8 +669,10 @@ class SerialProver:
         self.dabc = prep(pk.delta_abc_g1, nw, 1)
         torch.cuda.synchronize()
         self.pipe = _G1Pipeline([self.nv + 2, m + 1, nw])
-        self.g2_ws_bytes = int(L.ozk_var_msm_workspace_bytes(self.nv + 2, 2))
+        self.g2_ws_bytes = int(L.ozk_var_msm_head_workspace_bytes(self.nv + 2, 2))
         self.g2_ws = torch.empty(self.g2_ws_bytes, dtype=torch.uint8, device="cuda")
+        self.g2_tail_bytes = int(L.ozk_var_msm_tail_bytes(self.nv + 2, 2))
+        self.g2_tail = torch.empty(self.g2_tail_bytes, dtype=torch.uint8, device="cuda")
         self.s_g2 = torch.cuda.Stream()
         # witness map + C's share: dispatched ahead of the MSMs that do not depend on them (the H MSM waits for the map)
         self.s_fin = torch.cuda.Stream(priority=-1)
@@ -719,8 +723,11 @@ class SerialProver:
         # first: its tail is the longest latency-bound chain of the proof and hides under the G1 accumulations.
         self.s_g2.wait_event(ready)
         with torch.cuda.stream(self.s_g2):
-            _lib.check(L.ozk_var_msm_prepared_dev(_ptr(self.qb2), _ptr(d_full_s), nv + 2, 2, _ptr(o2[0]), _ptr(self.g2_ws),
-                                                  self.g2_ws_bytes, _stream()))
+            _lib.check(L.ozk_var_msm_head_prepared_dev(_ptr(self.qb2), _ptr(d_full_s), nv + 2, 2, _ptr(self.g2_ws),
+                                                       self.g2_ws_bytes, _ptr(self.g2_tail), self.g2_tail_bytes, _stream(),
+                                                       None))
+            _lib.check(L.ozk_var_msm_tail_mode_dev(nv + 2, 2, _ptr(self.g2_tail), self.g2_tail_bytes, _ptr(o2[0]),
+                                                   _stream(), None, 1))
             g2_done = torch.cuda.Event()
             g2_done.record(self.s_g2)
         # witness map (SerialProver.java:36-41): constraint evaluations (R1CStoQAP.java:143-160,195-199) and the
