@@ -527,6 +527,51 @@ OZK_HD auto mul2(const FeL<P, B1, LU1>& a, const Fe<P, B2>& b, const FeL<P, B3, 
   return mul2(an, b, cn, d);
 }
 
+// ---- general product sums over loose factors (the lazily carried Fq2 arithmetic, fq2.cuh).  Every factor is an
+// FeL (a normalised element is FeL<., ., 2>: loose()); the 64-bit column accumulator holds
+//     sum over the products of 9 (LUx 2^28)(LUy 2^28) + 9 2^58 (the m p terms) + carry < 2^64
+// as long as the LU products add up to at most 24 (a product of two normalised factors counts 4).
+template <class P, int B>
+OZK_HD FeL<P, B, 2> loose(const Fe<P, B>& a) { return FeL<P, B, 2>(a); }
+template <class P, int B1, int L1, int B2, int L2>
+OZK_HD auto add_nc(const FeL<P, B1, L1>& a, const FeL<P, B2, L2>& b) {
+  FeL<P, B1 + B2, L1 + L2> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + b.l[i];
+  return r;
+}
+template <class P, int B1, int L1>
+OZK_HD auto dbl_nc(const FeL<P, B1, L1>& a) {
+  FeL<P, 2 * B1, 2 * L1> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = a.l[i] << 1;
+  return r;
+}
+template <class P, int B, int LU>
+OZK_HD Fe<P, B> as_fe(const FeL<P, B, LU>& a) {  // the limbs as they are, for the multiplier only
+  Fe<P, B> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = a.l[i];
+  return r;
+}
+template <class P, int B1, int L1, int B2, int L2>
+OZK_HD auto mul_ll(const FeL<P, B1, L1>& a, const FeL<P, B2, L2>& b) {
+  static_assert(L1 * L2 <= 24, "loose factors too wide for the 64-bit column accumulator");
+  return mul(as_fe(a), as_fe(b));
+}
+template <class P, int B1, int L1, int B2, int L2, int B3, int L3, int B4, int L4>
+OZK_HD auto mul2_ll(const FeL<P, B1, L1>& a, const FeL<P, B2, L2>& b, const FeL<P, B3, L3>& c, const FeL<P, B4, L4>& d) {
+  static_assert(L1 * L2 + L3 * L4 <= 24, "loose factors too wide for the 64-bit column accumulator");
+  return mul2(as_fe(a), as_fe(b), as_fe(c), as_fe(d));
+}
+template <class P, int B1, int L1, int B2, int L2, int B3, int L3, int B4, int L4, int B5, int L5, int B6, int L6, int B7,
+          int L7, int B8, int L8>
+OZK_HD auto mul4_ll(const FeL<P, B1, L1>& a, const FeL<P, B2, L2>& b, const FeL<P, B3, L3>& c, const FeL<P, B4, L4>& d,
+                    const FeL<P, B5, L5>& e, const FeL<P, B6, L6>& f, const FeL<P, B7, L7>& g, const FeL<P, B8, L8>& h) {
+  static_assert(L1 * L2 + L3 * L4 + L5 * L6 + L7 * L8 <= 24, "loose factors too wide for the 64-bit column accumulator");
+  return mul4(as_fe(a), as_fe(b), as_fe(c), as_fe(d), as_fe(e), as_fe(f), as_fe(g), as_fe(h));
+}
+
 // if (a >= K*p) a -= K*p          (branch-free, signed borrow propagation)
 template <int K, class P, int B>
 OZK_HD auto csub(const Fe<P, B>& a) {

@@ -130,6 +130,52 @@ OZK_HD auto mulsub(const Fe2<B1>& a, const Fe2<B2>& b, const Fe2<B3>& c, const F
     return sub(mul(a, b), mul(c, d));
   }
 }
+// ---- the same products with the carry passes left out wherever the consumer is the multiplier (fp29.cuh FeL):
+// -a1 and -c enter their products as K p - x without a carry, the sums and differences inside the squaring go
+// straight into its one product, a - b - 2c takes one carry instead of three.  The level-1 mixed addition of G2
+// (msm_var.cuh RunAccLds::accumulate_q) spends 27 carry passes per addition in the carried forms above, 8 in these.
+template <int B1, int B2>
+OZK_HD Fe2<32> mul_lz(const Fe2<B1>& a, const Fe2<B2>& b) {
+  static_assert(lazy_ok(B1, B2), "reduce the factors first");
+  Fe2<32> r;
+  r.c0 = Fe<FqParams, 32>(mul2_ll(loose(a.c0), loose(b.c0), neg_nc(a.c1), loose(b.c1)));
+  r.c1 = Fe<FqParams, 32>(mul2(a.c0, b.c1, a.c1, b.c0));
+  return r;
+}
+template <int B1>
+OZK_HD Fe2<32> sqr_lz(const Fe2<B1>& a) {
+  static_assert(B1 <= 32, "reduce the argument first");
+  const auto t = mul_ll(dbl_nc(loose(a.c0)), loose(a.c1));
+  const auto d = mul_ll(add_nc(loose(a.c0), loose(a.c1)), sub_nc(a.c0, a.c1));
+  Fe2<32> r;
+  r.c0 = Fe<FqParams, 32>(reduce_to<32>(d));
+  r.c1 = Fe<FqParams, 32>(reduce_to<32>(t));
+  return r;
+}
+template <int B1, int B2, int B3, int B4>
+OZK_HD auto mulsub_lz(const Fe2<B1>& a, const Fe2<B2>& b, const Fe2<B3>& c, const Fe2<B4>& d) {
+  constexpr long long N1 = 16LL * (B1 / 16 + 1), N3 = 16LL * (B3 / 16 + 1);
+  constexpr long long BB0 = (long long)B1 * B2 + N1 * B2 + N3 * B4 + (long long)B3 * B4;
+  constexpr long long BB1 = 2LL * B1 * B2 + 2 * N3 * B4;
+  constexpr long long BB = BB0 > BB1 ? BB0 : BB1;
+  static_assert(BB <= (long long)MONT_SLACK * 256, "Montgomery input bounds too large");
+  constexpr int BO = 16 + ceil_div(BB, 16 * MONT_SLACK);
+  const auto na1 = neg_nc(a.c1);
+  const auto nc0 = neg_nc(c.c0);
+  const auto nc1 = neg_nc(c.c1);
+  Fe2<BO> r;
+  r.c0 = Fe<FqParams, BO>(mul4_ll(loose(a.c0), loose(b.c0), na1, loose(b.c1), nc0, loose(d.c0), loose(c.c1), loose(d.c1)));
+  r.c1 = Fe<FqParams, BO>(mul4_ll(loose(a.c0), loose(b.c1), loose(a.c1), loose(b.c0), nc0, loose(d.c1), nc1, loose(d.c0)));
+  return r;
+}
+template <int B1, int B2, int B3>
+OZK_HD auto sub_sub2(const Fe2<B1>& a, const Fe2<B2>& b, const Fe2<B3>& c) {
+  Fe2<B1 + 16 * (B2 / 16 + 1) + 32 * (B3 / 16 + 1)> r;
+  r.c0 = sub_sub2(a.c0, b.c0, c.c0);
+  r.c1 = sub_sub2(a.c1, b.c1, c.c1);
+  return r;
+}
+
 template <int B>
 OZK_HD Fe2<B> select_el(bool c, const Fe2<B>& a, const Fe2<B>& b) {
   Fe2<B> r;
@@ -239,11 +285,12 @@ struct G2Cfg {
   static constexpr bool WIDE_INPUTS = false;
   static constexpr bool LDS_ACC = true;   // level-1 accumulator in LDS (msm_var.cuh RunAccLds)
   static constexpr bool LAZY_MADD = false;
+  static constexpr bool LAZY_FQ2 = true;  // RunAccLds::accumulate_q uses mul_lz / sqr_lz / mulsub_lz / sub_sub2
   using EX = Fe2<144>;
   using EY = Fe2<112>;
   using EZ = Fe2<112>;
   using EA = Fe2<17>;
-  using XX = Fe2<144>;   // sqr - (PPP + 2Q) < 2p + 7p
+  using XX = Fe2<176>;   // sqr - PPP - 2Q with its biases: < 2p + 3p + 6p (the carried form: 2p + 7p)
   using XY = Fe2<80>;    // mul - mul < 2p + 3p
   using XZZ = Fe2<32>;
   using XZZZ = Fe2<32>;
