@@ -219,7 +219,12 @@ static int stage_wait(HostCtx* c, int b) {
   if (c->stage_busy[b]) {
     StatTimer tm(host_call_stats().stage_wait_ms);
     host_call_stats().stage_waits++;
+    const auto t0 = std::chrono::steady_clock::now();
     OZK_HIP(hipEventSynchronize(c->stage_free[b]));
+    if (env_int("OZK_HOST_TRACE", 0)) {
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      if (ms > 1.0) fprintf(stderr, "[ozk] stage_wait #%d buffer %d: %.2f ms\n", host_call_stats().stage_waits, b, ms);
+    }
     c->stage_busy[b] = false;
   }
   return OZK_OK;

@@ -40,16 +40,24 @@ def fresh(a):
 
 
 def run(name, fn, make_inputs, reps, moved_mib, dev_ms=None):
-    times = []
+    times, stats = [], []
     for _ in range(reps + 1):
         args = make_inputs()
         t0 = time.perf_counter()
         fn(*args)
         times.append((time.perf_counter() - t0) * 1e3)
+        st = (ctypes.c_double * 10)()
+        L.ozk_host_call_stats(st)
+        stats.append(list(st))
     warm = sorted(times[1:])
     extra = "" if dev_ms is None else "  | device-resident %.2f ms" % dev_ms
     print("%-46s first %8.2f ms | min %7.2f  median %7.2f ms | %5.0f MiB over PCIe%s   all: %s"
           % (name, times[0], warm[0], warm[len(warm) // 2], moved_mib, extra, " ".join("%.1f" % t for t in times[1:])), flush=True)
+    k = max(range(1, len(times)), key=lambda i: times[i])
+    if times[k] > 1.5 * warm[0]:   # where the slowest call's time went, as the library saw it
+        f = ("acquire", "reserve", "stage_wait", "memcpy_in", "memcpy_out", "enqueue", "sync")
+        print("    slowest call %.1f ms, inside the library %.1f: " % (times[k], stats[k][9])
+              + "  ".join("%s %.2f" % (n, v) for n, v in zip(f, stats[k])), flush=True)
 
 
 def main():
