@@ -11,12 +11,15 @@ scalars) to the 192-byte affine-normalised result.  With N GPUs every rank owns 
 partials over RCCL and each adds them up with the HIP point-sum kernel — the
 Spark `mapPartitions -> reduce(add)` of VariableBaseMSM.java:777-783.
 
-Steps overlap: by default two MSMs are in flight on a head stream and a tail stream
-(device.VarMsmPipeline); `--schedule streams` issues complete MSMs round-robin on independent
-streams instead (see --help).  Prints ONE JSON line (rank 0).  `value` = N * 2^20 * K / wall-time / 1e6 Mscalar-mul/s,
+Steps overlap: by default three MSMs are in flight as sort | bucket accumulation | tail on their own streams
+(device.VarMsmPipeline3; `--schedule pipeline` is round 2's head | tail form, `--schedule streams` issues complete
+MSMs round-robin on independent streams; see --help).  Prints ONE JSON line (rank 0).  `value` = N * 2^20 * K / wall-time / 1e6 Mscalar-mul/s,
 max wall-time over ranks, inputs resident in HBM when the timed region starts.
 `roofline` is for the dominant kernel (level-1 bucket accumulation): algorithmic bytes
-(128 B per scalar-mul) / its HIP-event duration, against the 8 TB/s HBM peak.
+(128 B per scalar-mul) / its duration inside the timed region, against the 8 TB/s HBM peak.  The
+duration comes from the device clock the kernel's own waves stamp (`kernel_ms`); the same steps are then repeated with
+HIP start / stop events on every level-1 dispatch (`kernel_ms_hip_events`: an event-carrying dispatch slows the
+three-stage schedule, so it stays out of the timed region), and five lone MSMs give the kernel alone (`kernel_ms_alone`).
 `cpu_baseline` times the C oracle (oracle/ozk_oracle.c, a single-thread C port of the
 reference's serial Java pippengerMSM) on the SAME 2^20 inputs on one host core — rank 0,
 N = 1 only — and the bench asserts the GPU bytes equal the CPU bytes.

@@ -80,6 +80,8 @@ struct PassArgs {
   int n, logn;
   int sbits;        // stages already done = log2 of the butterfly distance entering this pass
   int K;            // stages in this pass
+  const u32* scale; // LAST pass only, or null: out[i] is multiplied by scale[i] (n x 8 words, Montgomery form) on its
+                    // way out — the coset / 1-over-m scalings of the witness map ride on the transform before them
 };
 
 template <int B, int TILE>
@@ -157,7 +159,8 @@ __device__ __forceinline__ void gstore(const PassArgs& a, int T, int logT, u32 m
   const u32 i = tile_index<FIRST>(a, blockIdx.x, T, logT, mid, ul);
   u32 o[8];
   if (last) {
-    pack(canonical(v), o);
+    if (a.scale != nullptr) pack(canonical(mul(v, ElemTraits<Fe<FrP, 16>>::load(a.scale + (size_t)i * 8))), o);
+    else pack(canonical(v), o);
     uint4* dst = reinterpret_cast<uint4*>(a.out + (size_t)i * a.out_stride);
     dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
     dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
@@ -331,7 +334,8 @@ __device__ __forceinline__ void fft_store_tile(u32* lds, const PassArgs& a, int 
     fe_carry(v);   // (a pair leaves its outputs uncarried in LDS)
     u32 o[8];
     if (last) {
-      pack(canonical(v), o);
+      if (a.scale != nullptr) pack(canonical(mul(v, ElemTraits<Fe<FrP, 16>>::load(a.scale + (size_t)i * 8))), o);
+      else pack(canonical(v), o);
       uint4* dst = reinterpret_cast<uint4*>(a.out + (size_t)i * a.out_stride);
       dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
       dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
@@ -465,9 +469,10 @@ static void fft_build_twiddles(const u32* d_omega, int n, u32* small, u32* tw, h
 // the transform proper: d_in (n x 8 words) -> d_out (n x out_stride words), in place allowed only
 // through the two ping-pong buffers (d_out may be one of them only if it is not read by the last pass)
 static int fft_core(const u32* d_in, int n, const u32* tw, u32* d_out, int out_stride, u32* buf0, u32* buf1,
-                    hipStream_t st) {
+                    hipStream_t st, const u32* scale = nullptr) {
   const int logn = ilog2((uint32_t)n);
   if (n < FFT_TILE_SMALL) {
+    if (scale) return fail(OZK_E_INTERNAL, "output scaling needs the tiled transform");
     hipLaunchKernelGGL(k_fft_small, dim3(1), dim3(FFT_THREADS), 0, st, d_in, d_out, tw, n, logn, buf0, out_stride);
     OZK_HIP(hipGetLastError());
     return OZK_OK;
@@ -507,6 +512,7 @@ static int fft_core(const u32* d_in, int n, const u32* tw, u32* d_out, int out_s
     a.logn = logn;
     a.sbits = sbits;
     a.K = K;
+    a.scale = last ? scale : nullptr;
     const int tiles = n / tile, li = last ? 1 : 0;
 #define OZK_FFT_LAUNCH(TL)                                                                                          \
   if (pass == 0)                                                                                                    \
@@ -549,6 +555,7 @@ struct FftPlan {
   uint8_t omega[32], g[32];
   uint8_t* mem = nullptr;
   u32 *tw_f = nullptr, *tw_i = nullptr, *pw_g = nullptr, *pw_gi = nullptr, *small = nullptr;
+  u32 *sc_g = nullptr, *sc_gi = nullptr;
   QapConsts* consts = nullptr;
   hipEvent_t ready = nullptr;
   unsigned long long last_use = 0;
@@ -717,9 +724,24 @@ __global__ void __launch_bounds__(256) k_qap_pointwise(const u32* a, const u32* 
   dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
 }
 
+// full[i] = base^i * k for i < n, Montgomery form (pw: two-level power table of base, k_mont = k R): the table the
+// last pass of a transform multiplies its outputs by (PassArgs::scale)
+__global__ void __launch_bounds__(256) k_scale_table(const u32* __restrict__ pw, int lo, int n,
+                                                     const u32* __restrict__ k_mont, u32* __restrict__ full) {
+  using ET = ElemTraits<Fe<FrP, 16>>;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const auto p = mul(ET::load(pw + (size_t)(i % lo) * 8), ET::load(pw + (size_t)(lo + i / lo) * 8));
+  u32 o[8];
+  pack(canonical(mul(p, ET::load(k_mont))), o);
+  uint4* dst = reinterpret_cast<uint4*>(full + (size_t)i * 8);
+  dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+  dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+}
+
 struct QapLayout {
   QapConsts* consts;
-  u32 *small, *tw_f, *tw_i, *pw_g, *pw_gi, *buf[2], *va, *vb, *vc;
+  u32 *small, *tw_f, *tw_i, *pw_g, *pw_gi, *sc_g, *sc_gi, *buf[2], *va, *vb, *vc;
   size_t bytes;
   int lo;
 };
@@ -735,6 +757,8 @@ static QapLayout qap_layout(int m, void* wsp, size_t wsb) {
   L.tw_i = b.take<u32>((size_t)half * 8);
   L.pw_g = b.take<u32>((size_t)(TW_LO + hi) * 8);
   L.pw_gi = b.take<u32>((size_t)(TW_LO + hi) * 8);
+  L.sc_g = b.take<u32>((size_t)m * 8);    // g^i / m and g^-i / m for every i (only used without the plan cache)
+  L.sc_gi = b.take<u32>((size_t)m * 8);
   L.buf[0] = b.take<u32>((size_t)m * 8);
   L.buf[1] = b.take<u32>((size_t)m * 8);
   L.va = b.take<u32>((size_t)m * 8);
@@ -746,8 +770,8 @@ static QapLayout qap_layout(int m, void* wsp, size_t wsb) {
 }
 
 // the domain-dependent part of the witness map: constants, both twiddle tables, both coset power tables
-static int qap_build_tables(QapConsts* consts, u32* small, u32* tw_f, u32* tw_i, u32* pw_g, u32* pw_gi, int m,
-                            const uint8_t* omega_host, const uint8_t* g_host, hipStream_t st) {
+static int qap_build_tables(QapConsts* consts, u32* small, u32* tw_f, u32* tw_i, u32* pw_g, u32* pw_gi, u32* sc_g,
+                            u32* sc_gi, int m, const uint8_t* omega_host, const uint8_t* g_host, hipStream_t st) {
   OZK_HIP(hipMemcpyAsync(consts->omega, omega_host, 32, hipMemcpyHostToDevice, st));
   OZK_HIP(hipMemcpyAsync(consts->g, g_host, 32, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(k_qap_consts, dim3(4), dim3(64), 0, st, consts, m);
@@ -756,6 +780,8 @@ static int qap_build_tables(QapConsts* consts, u32* small, u32* tw_f, u32* tw_i,
   const int hi = (m + TW_LO - 1) / TW_LO + 1;
   hipLaunchKernelGGL(k_tw_small, dim3((TW_LO + hi + 255) / 256), dim3(256), 0, st, consts->g, TW_LO, hi, pw_g);
   hipLaunchKernelGGL(k_tw_small, dim3((TW_LO + hi + 255) / 256), dim3(256), 0, st, consts->g_inv, TW_LO, hi, pw_gi);
+  hipLaunchKernelGGL(k_scale_table, dim3((m + 255) / 256), dim3(256), 0, st, pw_g, TW_LO, m, consts->m_inv_mont, sc_g);
+  hipLaunchKernelGGL(k_scale_table, dim3((m + 255) / 256), dim3(256), 0, st, pw_gi, TW_LO, m, consts->m_inv_mont, sc_gi);
   OZK_HIP(hipGetLastError());
   return OZK_OK;
 }
@@ -803,8 +829,12 @@ static int plan_get(int n, const uint8_t* omega, const uint8_t* g, hipStream_t s
       u32* twi = g ? b.take<u32>((size_t)half * 8) : nullptr;
       u32* pg = g ? b.take<u32>((size_t)(TW_LO + hi) * 8) : nullptr;
       u32* pgi = g ? b.take<u32>((size_t)(TW_LO + hi) * 8) : nullptr;
+      u32* sg = g ? b.take<u32>((size_t)n * 8) : nullptr;
+      u32* sgi = g ? b.take<u32>((size_t)n * 8) : nullptr;
       b.take<u32>(64);
       if (dst) {
+        dst->sc_g = sg;
+        dst->sc_gi = sgi;
         dst->consts = c;
         dst->small = sm;
         dst->tw_f = twf;
@@ -824,7 +854,7 @@ static int plan_get(int n, const uint8_t* omega, const uint8_t* g, hipStream_t s
     }
     carve(p.mem, &p);
     if (g) {
-      rc = qap_build_tables(p.consts, p.small, p.tw_f, p.tw_i, p.pw_g, p.pw_gi, n, omega, g, st);
+      rc = qap_build_tables(p.consts, p.small, p.tw_f, p.tw_i, p.pw_g, p.pw_gi, p.sc_g, p.sc_gi, n, omega, g, st);
     } else {
       hipError_t e2 = hipMemcpyAsync(p.consts->omega, omega, 32, hipMemcpyHostToDevice, st);
       if (e2 != hipSuccess) rc = fail(OZK_E_NO_DEVICE, "hipMemcpyAsync failed: %s", hipGetErrorString(e2));
@@ -866,23 +896,32 @@ static int qap_witness_dev(const void* d_A, const void* d_B, const void* d_C, in
     L.tw_i = pl->tw_i;
     L.pw_g = pl->pw_g;
     L.pw_gi = pl->pw_gi;
+    L.sc_g = pl->sc_g;
+    L.sc_gi = pl->sc_gi;
   } else {
-    int brc = qap_build_tables(L.consts, L.small, L.tw_f, L.tw_i, L.pw_g, L.pw_gi, m, omega_host, g_host, st);
+    int brc = qap_build_tables(L.consts, L.small, L.tw_f, L.tw_i, L.pw_g, L.pw_gi, L.sc_g, L.sc_gi, m, omega_host, g_host, st);
     if (brc) return brc;
   }
   const int TB = 256, nb = (m + TB - 1) / TB;
   const u32* in[3] = {(const u32*)d_A, (const u32*)d_B, (const u32*)d_C};
   u32* v[3] = {L.va, L.vb, L.vc};
   int rc;
+  // The scalings ride on the inverse transforms before them: their last pass multiplies every output by g^i / m
+  // (resp. g^-i / m) from a full table of the plan instead of four extra passes over the data (44 k_coset_scale
+  // launches = 0.22 of the 2.07 ms of round 2's map at 2^21).  Transforms too small for the tiled kernel keep the
+  // separate kernel.
+  const bool fold = m >= FFT_TILE_SMALL && env_int("OZK_QAP_FOLD_SCALE", 1) != 0;
   for (int k = 0; k < 3; k++) {
     // coefficients (times m), then a_i g^i / m, then the evaluations on the coset
-    if ((rc = fft_core(in[k], m, L.tw_i, v[k], 8, L.buf[0], L.buf[1], st))) return rc;
-    hipLaunchKernelGGL(k_coset_scale, dim3(nb), dim3(TB), 0, st, v[k], m, 8, L.pw_g, TW_LO, L.consts->m_inv_mont);
+    if ((rc = fft_core(in[k], m, L.tw_i, v[k], 8, L.buf[0], L.buf[1], st, fold ? L.sc_g : nullptr))) return rc;
+    if (!fold)
+      hipLaunchKernelGGL(k_coset_scale, dim3(nb), dim3(TB), 0, st, v[k], m, 8, L.pw_g, TW_LO, L.consts->m_inv_mont);
     if ((rc = fft_core(v[k], m, L.tw_f, v[k], 8, L.buf[0], L.buf[1], st))) return rc;
   }
   hipLaunchKernelGGL(k_qap_pointwise, dim3(nb), dim3(TB), 0, st, L.va, L.vb, L.vc, m, L.consts->zinv_mont, L.va);
-  if ((rc = fft_core(L.va, m, L.tw_i, (u32*)d_H, 8, L.buf[0], L.buf[1], st))) return rc;
-  hipLaunchKernelGGL(k_coset_scale, dim3(nb), dim3(TB), 0, st, (u32*)d_H, m, 8, L.pw_gi, TW_LO, L.consts->m_inv_mont);
+  if ((rc = fft_core(L.va, m, L.tw_i, (u32*)d_H, 8, L.buf[0], L.buf[1], st, fold ? L.sc_gi : nullptr))) return rc;
+  if (!fold)
+    hipLaunchKernelGGL(k_coset_scale, dim3(nb), dim3(TB), 0, st, (u32*)d_H, m, 8, L.pw_gi, TW_LO, L.consts->m_inv_mont);
   OZK_HIP(hipMemsetAsync((u32*)d_H + (size_t)m * 8, 0, 32, st));  // coefficientsH.add(zero), R1CStoQAP.java:225
   OZK_HIP(hipGetLastError());
   return OZK_OK;

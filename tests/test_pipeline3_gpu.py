@@ -82,6 +82,33 @@ def test_three_stage_pipeline_vs_oracle_small():
     assert got == wants
 
 
+@pytest.mark.parametrize("n", [7, 300, 1 << 12])
+def test_three_stage_pipeline_g2_equals_single_calls(n):
+    """the same schedule over G2 (LDS-resident accumulator, Fq2 group law) against the single-call path"""
+    import numpy as np
+    import torch
+    from octopuszk_amd import device as dev
+    rng = random.Random(300 + n)
+    G = o.G2
+    pts = [G.to_affine(G.mul(G.one, rng.randrange(1, 1 << 64))) for _ in range(min(n, 48))]
+    bases = [pts[i % len(pts)] for i in range(n)]
+    d_bases = torch.from_numpy(np.frombuffer(b"".join(o.g2_to_wire(b) for b in bases), dtype=np.uint8).copy()).cuda()
+    inputs = [torch.from_numpy(_scalars(n, 70 + i)).cuda() for i in range(5)]
+    ws = dev.VarMsmWorkspace(n, 2)
+    serial = []
+    for d_sc in inputs:
+        out = ws.run(d_bases, d_sc)
+        torch.cuda.synchronize()
+        serial.append(bytes(out.cpu().numpy()))
+    pipe = dev.VarMsmPipeline3(n, 2)
+    ts = [pipe.submit(d_bases, d_sc) for d_sc in inputs[:4]]
+    torch.cuda.synchronize()
+    assert [bytes(pipe.outs[t % pipe.depth].cpu().numpy()) for t in ts] == serial[:4]
+    want = o.g2_out_le(G.to_affine(o.naive_msm(G, [int.from_bytes(bytes(inputs[0].cpu().numpy()[32 * i:32 * i + 32]), "little")
+                                                   for i in range(n)], bases)))
+    assert serial[0] == want
+
+
 @pytest.mark.parametrize("logn", [20, 21])
 def test_three_stage_full_size_discrete_log_identity(logn):
     """2^20 (the bench workload) and 2^21 (bins of several register tiles in k_sort2): sum s_i (k_i G) =
