@@ -23,6 +23,19 @@ static void fe_binop(int op, const u32* a, const u32* b, u32* out) {
     case 6: from_mont(dbl(dbl(dbl(x))), wo); break;
     case 7: { auto t = sub(sub(sub(x, y), y), y); from_mont(reduce_to<32>(t), wo); break; }
     case 8: { u32 t[8]; pack(canonical(x), t); auto z = unpack<P, 16>(t); from_mont(z, wo); break; }
+    // ---- loose (un-normalised) elements, fp29.cuh FeL: every result must equal the carried computation
+    case 20: from_mont(mul(sub_nc(x, y), y), wo); break;                                   // (x - y) y
+    case 21: from_mont(mul(select_el(true, neg_nc(x), x), y), wo); break;                  // (-x) y
+    case 22: from_mont(sub_sub2(sqr(x), mul(x, y), sqr(y)), wo); break;                    // x^2 - x y - 2 y^2
+    case 23: from_mont(mul_ll(add_nc(loose(x), loose(y)), sub_nc(x, y)), wo); break;       // x^2 - y^2
+    case 24: from_mont(mul2_ll(loose(x), loose(y), neg_nc(y), loose(x)), wo); break;       // x y - y x = 0
+    case 25: from_mont(mul2(sub_nc(x, y), x, neg_nc(y), y), wo); break;                    // (x - y) x - y^2
+    case 26: from_mont(normalise(add_nc(dbl_nc(sub_nc(x, y)), loose(y))), wo); break;      // 2 (x - y) + y
+    case 27: {                                                                             // four loose products
+      const auto r = mul4_ll(loose(x), loose(y), neg_nc(x), loose(y), neg_nc(y), loose(x), loose(y), loose(x));
+      from_mont(r, wo);                                                                    // x y - x y - y x + y x = 0
+      break;
+    }
     default: memset(wo, 0, 32);
   }
   memcpy(out, wo, 32);
@@ -83,6 +96,14 @@ extern "C" void hc_g1_op(int op, const u32* pw, const u32* qw, int k, u32* out) 
       else r = xyzz_to_jac(xyzz_add(xyzz_add(z, a), z));            // infinity on either side: P+kQ
       break;
     }
+    case 12: case 13: case 14: {  // the level-1 form: lazily carried mixed additions with the digit's sign
+      Aff<A1> pa; pa.x = A1(reduce_to<17>(p.X)); pa.y = A1(reduce_to<17>(p.Y));
+      if (is_zero(p.Z)) { pa.x = A1(el_zero(pa.x)); pa.y = A1(el_zero(pa.x)); }
+      Xyzz<J1> a = xyzz_from_affine<J1>(pa);   // op 12: P + kQ, 13: P - kQ, 14: P + Q - Q + Q ...
+      for (int i = 0; i < k; i++) a = xyzz_madd_lazy(a, qa, op == 13 || (op == 14 && (i & 1)));
+      r = xyzz_to_jac(a);
+      break;
+    }
     default: r = p;
   }
   store_jac(r, out);
@@ -106,6 +127,16 @@ extern "C" void hc_fq2_op(int op, const u32* a, const u32* b, u32* out) {  // 16
       ElemTraits<Fe2<32>>::to_wire(Fe2<32>(reduce_to<32>(r)), out);
       break;
     }
+    // ---- the lazily carried forms (what the G2 level-1 addition uses)
+    case 7: ElemTraits<Fe2<32>>::to_wire(mul_lz(x, y), out); break;
+    case 8: ElemTraits<Fe2<32>>::to_wire(sqr_lz(x), out); break;
+    case 9: {  // a b - c d with unreduced (< 2p, < 3p) inputs, as accumulate_q feeds it
+      auto b2 = reduce_to<32>(sub(x, y));
+      auto r = mulsub_lz(reduce_to<32>(add(x, y)), b2, Fe2<80>(sub(dbl(x), y)), y);
+      ElemTraits<Fe2<32>>::to_wire(Fe2<32>(reduce_to<32>(r)), out);
+      break;
+    }
+    case 10: ElemTraits<Fe2<32>>::to_wire(Fe2<32>(reduce_to<32>(sub_sub2(sqr(x), mul(x, y), sqr(y)))), out); break;
     default: break;
   }
 }
@@ -140,6 +171,33 @@ extern "C" void hc_g2_op(int op, const u32* pw, const u32* qw, int k, u32* out) 
       else if (op == 9) r = xyzz_to_jac(xyzz_add(a, a));            // doubling branch: 2(P+kQ)
       else if (op == 10) r = xyzz_to_jac(xyzz_add(a, na));          // infinity
       else r = xyzz_to_jac(xyzz_add(xyzz_add(z, a), z));            // infinity on either side: P+kQ
+      break;
+    }
+    case 12: {  // the schedule of RunAccLds::accumulate_q (msm_var.cuh) over the lazily carried Fq2 products, k times
+      Aff<J2::EA> pa; pa.x = J2::EA(reduce_to<17>(p.X)); pa.y = J2::EA(reduce_to<17>(p.Y));
+      if (is_zero(p.Z)) { pa.x = J2::EA(el_zero(pa.x)); pa.y = J2::EA(el_zero(pa.x)); }
+      Xyzz<J2> a = xyzz_from_affine<J2>(pa);
+      for (int i = 0; i < k; i++) {
+        if (is_inf(qa)) continue;
+        if (is_zero(a.ZZ)) { a = xyzz_from_affine<J2>(qa); continue; }
+        const auto U2 = mul_lz(qa.x, a.ZZ);
+        const auto P = sub(U2, a.X);
+        const auto R = sub(mul_lz(qa.y, a.ZZZ), a.Y);
+        if (is_zero(P)) {
+          if (is_zero(R)) { a = xyzz_dbl_affine<J2>(qa); }
+          else { a.ZZ = J2::XZZ(el_zero(qa.x)); a.ZZZ = J2::XZZZ(el_zero(qa.x)); }
+          continue;
+        }
+        const auto Pr = reduce_to<32>(P);
+        const auto PP = sqr_lz(Pr);
+        const auto PPP = mul_lz(Pr, PP);
+        const auto ZZn = mul_lz(a.ZZ, PP), ZZZn = mul_lz(a.ZZZ, PPP);
+        const auto Q = mul_lz(reduce_to<32>(a.X), PP);
+        const auto X3 = sub_sub2(sqr_lz(reduce_to<32>(R)), PPP, Q);
+        const auto Y3 = mulsub_lz(reduce_to<32>(R), reduce_to<32>(sub(Q, X3)), a.Y, PPP);
+        a.X = J2::XX(X3); a.Y = J2::XY(Y3); a.ZZ = J2::XZZ(ZZn); a.ZZZ = J2::XZZZ(ZZZn);
+      }
+      r = xyzz_to_jac(a);
       break;
     }
     default: r = p;

@@ -89,6 +89,24 @@ def test_eq_mod_p(hc):
     assert hc.hc_fq_is_zero_after_sub(_w(0), _w(o.Q)) == 1
 
 
+@pytest.mark.parametrize("field,p", [("fq", o.Q), ("fr", o.R)])
+def test_loose_elements_equal_the_carried_computation(hc, field, p):
+    """fp29.cuh FeL (round 3): sums and differences whose carry pass is left out, as factors of single, dual and
+    quad products — same values as the normalised arithmetic, on the edge values that maximise the limbs."""
+    rng = random.Random(17)
+    vals = EDGE(p) + [p - 3, (1 << 254) % p, ((1 << 261) - 1) % p] + [rng.randrange(p) for _ in range(150)]
+    for i, a in enumerate(vals):
+        b = vals[(i * 11 + 5) % len(vals)]
+        assert fe_op(hc, field, 20, a, b) == (a - b) * b % p
+        assert fe_op(hc, field, 21, a, b) == (-a) * b % p
+        assert fe_op(hc, field, 22, a, b) == (a * a - a * b - 2 * b * b) % p
+        assert fe_op(hc, field, 23, a, b) == (a * a - b * b) % p
+        assert fe_op(hc, field, 24, a, b) == 0
+        assert fe_op(hc, field, 25, a, b) == ((a - b) * a - b * b) % p
+        assert fe_op(hc, field, 26, a, b) == (2 * (a - b) + b) % p
+        assert fe_op(hc, field, 27, a, b) == 0
+
+
 def _pw(P):
     return (ctypes.c_uint32 * 24)(*[(c >> (32 * i)) & 0xffffffff for c in P for i in range(8)])
 
@@ -141,6 +159,19 @@ def test_g1_group_law(hc):
     assert G.equals(g1_op(hc, 11, Pa, Qa, 7), G.add(P, G.mul(Qa, 7)))
     assert G.equals(g1_op(hc, 8, Pa, Qa, 0), G.add(P, Qa))          # ZZ == 1 on both sides
     assert G.equals(g1_op(hc, 8, Pa, Pa, 3), G.mul(P, 8))           # A == B: doubling inside the add
+    # the level-1 form (round 3): lazily carried mixed additions with the digit's sign
+    for Pa_, Qa_ in ((Pa, aff[1]), (aff[4], aff[5])):
+        Pj = Pa_
+        assert G.equals(g1_op(hc, 12, Pa_, Qa_, 150), G.add(Pj, G.mul(Qa_, 150)))
+        assert G.equals(g1_op(hc, 13, Pa_, Qa_, 150), G.add(Pj, G.negate(G.mul(Qa_, 150))))
+        assert G.equals(g1_op(hc, 14, Pa_, Qa_, 7), G.add(Pj, Qa_))        # + - + - + - +
+        assert G.equals(g1_op(hc, 14, Pa_, Qa_, 8), Pj)
+    assert G.equals(g1_op(hc, 12, Pa, Pa, 5), G.mul(P, 6))                 # doubling on the first step
+    assert G.equals(g1_op(hc, 13, Pa, G.negate(Pa), 5), G.mul(P, 6))       # ... through the negated y
+    assert G.is_zero(g1_op(hc, 13, Pa, Pa, 1))                             # P - P
+    assert G.equals(g1_op(hc, 13, Pa, Pa, 2), G.negate(P))                 # infinity, then a run start from -Q
+    assert G.equals(g1_op(hc, 13, G.zero, aff[2], 3), G.negate(G.mul(aff[2], 3)))
+    assert G.equals(g1_op(hc, 12, Pa, G.zero, 4), P)                       # infinity base
     # CurvesTest.java:27-82 identities on the HIP group law
     a = pts[3]
     assert G.equals(g1_op(hc, 0, G.mul(a, 76749407), G.mul(a, 44410867)), G.mul(a, 121160274))
@@ -170,6 +201,11 @@ def test_fq2_ops(hc):
         big = F.sub(F.add(F.add(a, a), F.add(a, a)), b)
         assert fq2_op(hc, 5, a, b) == F.mul(big, big)
         assert fq2_op(hc, 6, a, b) == F.sub(F.mul(a, big), F.mul(F.add(a, b), b))
+        # lazily carried forms (fq2.cuh mul_lz / sqr_lz / mulsub_lz / sub_sub2)
+        assert fq2_op(hc, 7, a, b) == F.mul(a, b)
+        assert fq2_op(hc, 8, a) == F.sqr(a)
+        assert fq2_op(hc, 9, a, b) == F.sub(F.mul(F.add(a, b), F.sub(a, b)), F.mul(F.sub(F.add(a, a), b), b))
+        assert fq2_op(hc, 10, a, b) == F.sub(F.sub(F.sqr(a), F.mul(a, b)), F.add(F.sqr(b), F.sqr(b)))
         if a != (0, 0):
             assert fq2_op(hc, 4, a) == F.inv(a)
 
@@ -213,4 +249,9 @@ def test_g2_group_law(hc):
     assert G.equals(g2_op(hc, 9, Pa, Qa, 5), G.twice(G.add(P, G.mul(Qa, 5))))
     assert G.is_zero(g2_op(hc, 10, Pa, Qa, 5))
     assert G.equals(g2_op(hc, 11, Pa, Qa, 5), G.add(P, G.mul(Qa, 5)))
+    # the level-1 schedule over the lazily carried Fq2 products (round 3)
+    assert G.equals(g2_op(hc, 12, Pa, aff[1], 80), G.add(P, G.mul(aff[1], 80)))
+    assert G.equals(g2_op(hc, 12, Pa, Pa, 3), G.mul(P, 4))
+    assert G.is_zero(g2_op(hc, 12, Pa, G.negate(Pa), 1))
+    assert G.equals(g2_op(hc, 12, G.zero, aff[2], 4), G.mul(aff[2], 4))
     assert G.equals(g2_op(hc, 8, Pa, Pa, 2), G.mul(P, 6))
