@@ -15,6 +15,9 @@ ap.add_argument("--logn", type=int, default=20)
 ap.add_argument("--prof", type=int, default=0)
 ap.add_argument("--prepared", action="store_true")
 ap.add_argument("--own-sort-stream", action="store_true")
+ap.add_argument("--sort-prio", type=int, default=None, help="run the sort stage on a new stream of this priority (-1 = high)")
+ap.add_argument("--acc-prio", type=int, default=None)
+ap.add_argument("--tail-prio", type=int, default=None)
 a = ap.parse_args()
 L = ozk.load()
 n = 1 << a.logn
@@ -24,6 +27,13 @@ d_sc = torch.from_numpy(sc.reshape(-1)).cuda()
 pipe = dev.VarMsmPipeline3(n, 1, depth=a.depth, tail_streams=a.tail_streams) if a.sched == "p3" else dev.VarMsmPipeline(n, 1, depth=2)
 b = pipe.prepare(bases) if a.prepared else bases
 st = torch.cuda.Stream() if a.own_sort_stream else torch.cuda.current_stream()
+if a.sort_prio is not None:
+    st = torch.cuda.Stream(priority=a.sort_prio)
+if a.acc_prio is not None and a.sched == "p3":
+    pipe.acc = torch.cuda.Stream(priority=a.acc_prio)
+if a.tail_prio is not None and a.sched == "p3":
+    pipe.tail_st = [torch.cuda.Stream(priority=a.tail_prio) for _ in pipe.tail_st]
+    pipe.side = pipe.tail_st[0]
 with torch.cuda.stream(st):
     for _ in range(6): t = pipe.submit(b, d_sc, prepared=a.prepared)
     torch.cuda.synchronize()
