@@ -15,6 +15,11 @@ ap.add_argument("--logn", type=int, default=20)
 ap.add_argument("--prof", type=int, default=0)
 ap.add_argument("--prepared", action="store_true")
 ap.add_argument("--own-sort-stream", action="store_true")
+ap.add_argument("--idle-ms", type=float, default=None, help="with --fit: sleep this long, run 5 warm-up MSMs, then time (the driver's bench form after an idle device)")
+ap.add_argument("--finish", action="store_true", help="with --fit: take every result on its tail stream as bench.py does")
+ap.add_argument("--gc-off", action="store_true")
+ap.add_argument("--ramp", action="store_true", help="after 300 ms of idle device: 16 back-to-back bursts of 10 MSMs, each timed, with the shader clock read after each")
+ap.add_argument("--fit", action="store_true", help="time 10/20/40/100/200 MSMs (three times each) in one process: total = c0 + K * s")
 ap.add_argument("--sort-prio", type=int, default=None, help="run the sort stage on a new stream of this priority (-1 = high)")
 ap.add_argument("--acc-prio", type=int, default=None)
 ap.add_argument("--tail-prio", type=int, default=None)
@@ -37,6 +42,53 @@ if a.tail_prio is not None and a.sched == "p3":
 with torch.cuda.stream(st):
     for _ in range(6): t = pipe.submit(b, d_sc, prepared=a.prepared)
     torch.cuda.synchronize()
+    if a.gc_off:
+        import gc; gc.disable()
+    if a.ramp:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from bench import sclk_mhz
+        import glob, re
+        def clk(name):
+            for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_" + name)):
+                try:
+                    for line in open(f):
+                        if "*" in line and not line.startswith("S"):
+                            m = re.search(r"(\d+)\s*Mhz", line, re.I)
+                            if m and int(m.group(1)) > 0: return m.group(1)
+                except OSError:
+                    pass
+            return "?"
+        for rnd in range(3):
+            torch.cuda.synchronize(); time.sleep(0.3); out = []
+            for burst in range(16):
+                t0 = time.perf_counter()
+                for _ in range(10): pipe.submit(b, d_sc, prepared=a.prepared)
+                torch.cuda.synchronize(); out.append("%.2f@%s/m%s/f%s/soc%s" % ((time.perf_counter() - t0) * 1e3, sclk_mhz(), clk("mclk"), clk("fclk"), clk("socclk")))
+            print("ms per burst of 10 @ sclk/mclk/fclk/socclk MHz:", " ".join(out), flush=True)
+        sys.exit(0)
+    if a.fit:
+        if a.prof: ozk.check(L.ozk_prof_enable(a.prof))
+        pts = []
+        for k in (10, 20, 40, 100, 200) * 3:
+            torch.cuda.synchronize()
+            if a.idle_ms is not None:
+                time.sleep(a.idle_ms / 1e3)
+                for _ in range(5): pipe.submit(b, d_sc, prepared=a.prepared)
+                torch.cuda.synchronize()
+            t0 = time.perf_counter(); hs = []
+            for _ in range(k):
+                h0 = time.perf_counter(); t = pipe.submit(b, d_sc, prepared=a.prepared)
+                if a.finish and t > 0:
+                    with torch.cuda.stream(pipe.stream_of(t - 1)): pipe.result(t - 1)
+                hs.append(time.perf_counter() - h0)
+            t_issued = time.perf_counter() - t0
+            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+            pts.append((k, dt * 1e3))
+            print("K=%3d total %.2f ms (%.3f per MSM); host: issue of all %.2f ms, submit median %.0f us, max %.0f us, first %.0f us"
+                  % (k, dt * 1e3, dt * 1e3 / k, t_issued * 1e3, sorted(hs)[k // 2] * 1e6, max(hs) * 1e6, hs[0] * 1e6), flush=True)
+        A = np.array([[1.0, k] for k, _ in pts]); y = np.array([t for _, t in pts])
+        c0, sl = np.linalg.lstsq(A, y, rcond=None)[0]
+        print("fit: total = %.2f ms + K * %.3f ms" % (c0, sl)); sys.exit(0)
     if a.prof: ozk.check(L.ozk_prof_enable(a.prof))
     t0 = time.perf_counter()
     for _ in range(a.reps): t = pipe.submit(b, d_sc, prepared=a.prepared)
