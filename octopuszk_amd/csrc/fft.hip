@@ -160,7 +160,7 @@ __device__ __forceinline__ void gstore(const PassArgs& a, int T, int logT, u32 m
   u32 o[8];
   if (last) {
     if (a.scale != nullptr) pack(canonical(mul(v, ElemTraits<Fe<FrP, 16>>::load(a.scale + (size_t)i * 8))), o);
-    else pack(canonical(v), o);
+    else pack(canonical_q(v), o);
     uint4* dst = reinterpret_cast<uint4*>(a.out + (size_t)i * a.out_stride);
     dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
     dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
@@ -169,7 +169,7 @@ __device__ __forceinline__ void gstore(const PassArgs& a, int T, int logT, u32 m
       dst[3] = make_uint4(0, 0, 0, 0);
     }
   } else {
-    pack(reduce_to<64>(v), o);
+    pack(reduce_q(v), o);
     uint4* dst = reinterpret_cast<uint4*>(a.out + (size_t)i * 8);
     dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
     dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
@@ -246,12 +246,28 @@ __device__ __forceinline__ void fft_stage2(u32* lds, const PassArgs& a, int T, i
     x10 = lds_load<BIN, TILE>(lds, e10);
     x11 = lds_load<BIN, TILE>(lds, e11);
   }
-  const auto w1 = TW::load(a.tw + (size_t)t1 * 8);
-  const auto w2a = TW::load(a.tw + (size_t)t2a * 8);
   const auto w2b = TW::load(a.tw + (size_t)t2b * 8);
-  const auto p = mul(w1, x01), q = mul(w1, x11);
-  const Fe<FrP, BIN + 32> a0 = add(x00, p), a1 = sub(x00, p), b0 = add_nc(x10, q), b1 = sub_nc(x10, q);
-  const auto u = mul(w2a, b0), v = mul(w2b, b1);
+  Fe<FrP, 24> p, q, u;   // products / reduce_q results: < 19 p / 16
+  Fe<FrP, BIN + 32> b1;
+  if constexpr (FIRST && Q == 1) {
+    // the first two stages of the transform: three of the four twiddles are omega^0 (low = lo = 0; w2b =
+    // omega^(n/4)).  A product by one is the operand itself, reduced: a table-row subtraction (reduce_q, ~30
+    // instructions) instead of a Montgomery multiplication (~330) — 3 of the 16 products of an 8-stage first pass
+    p = reduce_q(x01);
+    q = reduce_q(x11);
+    u = reduce_q(add(x10, q));
+    b1 = sub_nc(x10, q);
+  } else {
+    const auto w1 = TW::load(a.tw + (size_t)t1 * 8);
+    const auto w2a = TW::load(a.tw + (size_t)t2a * 8);
+    p = mul(w1, x01);
+    q = mul(w1, x11);
+    const Fe<FrP, BIN + 32> b0 = add_nc(x10, q);
+    b1 = sub_nc(x10, q);
+    u = mul(w2a, b0);
+  }
+  const Fe<FrP, BIN + 32> a0 = add(x00, p), a1 = sub(x00, p);
+  const auto v = mul(w2b, b1);
   if constexpr (DST_G) {
     const Fe<FrP, BIN + 64> y00 = add(a0, u), y10 = sub(a0, u), y01 = add(a1, v), y11 = sub(a1, v);
     gstore<FIRST, TILE>(a, T, logT, m00, ul, y00, last);
@@ -283,7 +299,9 @@ __device__ __forceinline__ void fft_stage1_from_global(u32* lds, const PassArgs&
 #pragma unroll
   for (int k = 0; k < 4; k += 2) {
     const auto x = gunpack(v0[k], v1[k]), y = gunpack(v0[k + 1], v1[k + 1]);
-    const auto t = mul(w, y);
+    Fe<FrP, 24> t;
+    if constexpr (FIRST) t = reduce_q(y);   // stage 1 of the transform: every twiddle is omega^0
+    else t = mul(w, y);
     lds_store<TILE>(lds, (m0 + k) * T + ul, Fe<FrP, 128>(add(x, t)));
     lds_store<TILE>(lds, (m0 + k + 1) * T + ul, Fe<FrP, 128>(sub(x, t)));
   }
@@ -335,7 +353,7 @@ __device__ __forceinline__ void fft_store_tile(u32* lds, const PassArgs& a, int 
     u32 o[8];
     if (last) {
       if (a.scale != nullptr) pack(canonical(mul(v, ElemTraits<Fe<FrP, 16>>::load(a.scale + (size_t)i * 8))), o);
-      else pack(canonical(v), o);
+      else pack(canonical_q(v), o);
       uint4* dst = reinterpret_cast<uint4*>(a.out + (size_t)i * a.out_stride);
       dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
       dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
@@ -344,7 +362,7 @@ __device__ __forceinline__ void fft_store_tile(u32* lds, const PassArgs& a, int 
         dst[3] = make_uint4(0, 0, 0, 0);
       }
     } else {
-      pack(reduce_to<64>(v), o);
+      pack(reduce_q(v), o);
       uint4* dst = reinterpret_cast<uint4*>(a.out + (size_t)i * 8);
       dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
       dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
@@ -501,7 +519,13 @@ static int fft_core(const u32* d_in, int n, const u32* tw, u32* d_out, int out_s
   }
   for (int pass = 0; pass < npass; pass++) {
     const int left = logn - sbits, passes_left = npass - pass;
-    const int K = (left + passes_left - 1) / passes_left;
+    int K = (left + passes_left - 1) / passes_left;
+    // the first pass opens with a stage PAIR when its K is even, and that pair costs one product instead of four
+    // (fft_stage2, FIRST && Q == 1): give it the even share when the later passes can take the rest
+    if (pass == 0 && npass > 1 && (K & 1) && env_int("OZK_FFT_EVEN_FIRST", 1)) {
+      if (K + 1 <= maxk && left - (K + 1) >= 3 * (npass - 1)) K += 1;
+      else if (K - 1 >= 4 && left - (K - 1) <= (npass - 1) * maxk) K -= 1;
+    }
     const bool last = pass == npass - 1;
     PassArgs a;
     a.in = src;

@@ -608,10 +608,48 @@ OZK_HD auto reduce_to(const Fe<P, B>& a) {
   }
 }
 
+// Reduction by an estimated quotient: a < B*p/16 (B up to 16*FE_MAXK) -> a - q*p < 17*p/16 in ONE subtraction of a
+// table row, instead of reduce_to's chain of conditional subtractions (three or four of them, ~37 instructions each,
+// from the bounds the FFT passes end with).  With ptop = p >> 232 (the top limb of p) and top = a >> 232:
+//   q = floor(top / (ptop + 1))   =>   q*p <= q*(ptop+1)*2^232 <= top*2^232 <= a            (never negative)
+//   a - q*p < (top+1)*2^232 - q*p <= (q+1)(ptop+1)*2^232 - q*ptop*2^232 = (ptop + q + 1)*2^232 < p*(1 + 2^-16)
+// The division is exact as floor(top*M / 2^53), M = ceil(2^53 / (ptop+1)): the product overshoots top/(ptop+1) by
+// less than top/2^53 < 2^-21 while the fractional part of top/(ptop+1) is at most 1 - 1/(ptop+1) = 1 - 2^-21.6.
+template <class P, int B>
+OZK_HD Fe<P, 17> reduce_q(const Fe<P, B>& a) {
+  static_assert(B <= 16 * FE_MAXK, "reduce_q: no table row for the largest quotient");
+  constexpr u64 D = (u64)P::P[8] + 1;
+  static_assert(D > (1u << 21) && D < (1u << 22), "reduce_q: the modulus must have 254 bits");
+  constexpr u64 M = ((1ull << 53) + D - 1) / D;
+  static_assert(M < (1ull << 32), "reduce_q: reciprocal does not fit a word");
+  static_assert((u64)B * D < (16ull << 31), "reduce_q: the top limb must stay below 2^31");
+  const u32 q = (u32)(((u64)a.l[8] * (u32)M) >> 53);   // v_mul_hi_u32 + shift
+  Fe<P, 17> r;
+  int32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const int32_t t = (int32_t)a.l[i] - (int32_t)P::KP[q][i] + c;
+    r.l[i] = (u32)t & FE_MASK;
+    c = t >> FE_W;
+  }
+  r.l[8] = (u32)((int32_t)a.l[8] - (int32_t)P::KP[q][8] + c);
+  return r;
+}
+
 // canonical representative in [0, p)
 template <class P, int B>
 OZK_HD Fe<P, 16> canonical(const Fe<P, B>& a) {
   auto u = csub<1>(Fe<P, 32>(reduce_to<32>(a)));  // < 2p, then one more conditional -p
+  Fe<P, 16> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = u.l[i];
+  return r;
+}
+
+// the same through reduce_q: two subtractions whatever the bound (canonical() needs five from B = 352)
+template <class P, int B>
+OZK_HD Fe<P, 16> canonical_q(const Fe<P, B>& a) {
+  auto u = csub<1>(reduce_q(a));
   Fe<P, 16> r;
 #pragma unroll
   for (int i = 0; i < 9; i++) r.l[i] = u.l[i];

@@ -41,6 +41,27 @@ static void fe_binop(int op, const u32* a, const u32* b, u32* out) {
   memcpy(out, wo, 32);
 }
 
+// reduce_q on k * a (k = 1, 2, 4, 6, 7: value bounds 85 .. 595), raw words out: must be < 17 p / 16 and = k a (mod p)
+template <class P>
+static void fe_reduce_q(int k, const u32* a, u32* out) {
+  u32 wa[8], wo[8];
+  memcpy(wa, a, 32);
+  const auto x = unpack<P, 85>(wa);
+  const auto x2 = add(x, x);
+  const auto x4 = add(x2, x2);
+  switch (k) {
+    case 1: pack(reduce_q(x), wo); break;
+    case 2: pack(reduce_q(x2), wo); break;
+    case 4: pack(reduce_q(x4), wo); break;
+    case 6: pack(reduce_q(add(x4, x2)), wo); break;
+    case 7: pack(reduce_q(add(add(x4, x2), x)), wo); break;
+    default: memset(wo, 0, 32);
+  }
+  memcpy(out, wo, 32);
+}
+extern "C" void hc_fq_reduce_q(int k, const u32* a, u32* out) { fe_reduce_q<FqParams>(k, a, out); }
+extern "C" void hc_fr_reduce_q(int k, const u32* a, u32* out) { fe_reduce_q<FrParams>(k, a, out); }
+
 extern "C" void hc_fq_op(int op, const u32* a, const u32* b, u32* out) { fe_binop<FqParams>(op, a, b, out); }
 extern "C" void hc_fr_op(int op, const u32* a, const u32* b, u32* out) { fe_binop<FrParams>(op, a, b, out); }
 extern "C" int hc_fq_is_zero_after_sub(const u32* a, const u32* b) {

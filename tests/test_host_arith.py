@@ -63,6 +63,28 @@ def test_field_ops(hc, field, p):
 
 
 @pytest.mark.parametrize("field,p", [("fq", o.Q), ("fr", o.R)])
+def test_reduce_q_one_subtraction_lands_below_17_16_p(hc, field, p):
+    """fp29.cuh reduce_q: quotient estimated from the top limb, one table-row subtraction.  Inputs around every
+    multiple of p and of (p >> 232) + 1 (where the estimate steps), the largest 256-bit values, random ones."""
+    rng = random.Random(11)
+    D = ((p >> 232) + 1) << 232
+    vals = [0, 1, (1 << 256) - 1, (1 << 256) - 2, 1 << 255, (1 << 232) - 1, 1 << 232]
+    for k in range(1, 6):
+        for d in (-2, -1, 0, 1, 2):
+            vals += [v for v in (k * p + d, k * D + d, k * D + d - (1 << 232)) if 0 <= v < (1 << 256)]
+    vals += [rng.randrange(1 << 256) for _ in range(300)]
+    fn = getattr(hc, "hc_%s_reduce_q" % field)
+    for a in vals:
+        for k in (1, 2, 4, 6, 7):
+            out = (ctypes.c_uint32 * 8)()
+            fn(k, _w(a), out)
+            got = _r(out)
+            assert got % p == k * a % p, (hex(a), k)
+            assert got < p + (p >> 4), (hex(a), k, got / p)
+            assert got < p + (48 << 232)          # the bound the derivation gives: (ptop + q + 1) 2^232
+
+
+@pytest.mark.parametrize("field,p", [("fq", o.Q), ("fr", o.R)])
 def test_safegcd_inversion(hc, field, p):
     # the divstep inversion against modular exponentiation, edge values, zero, non-canonical input
     rng = random.Random(8)
