@@ -24,6 +24,7 @@ namespace ozk {
 constexpr size_t STAGE_BYTES = (size_t)16 << 20;
 constexpr int STAGE_RING = 3;
 constexpr int MAX_SLICES = 16;
+constexpr size_t RESULT_BYTES = (size_t)64 << 10;
 
 struct HostCtx {
   int device = -1;
@@ -36,6 +37,7 @@ struct HostCtx {
   uint8_t* stage[STAGE_RING] = {nullptr, nullptr, nullptr};  // pinned host
   hipEvent_t stage_free[STAGE_RING] = {nullptr, nullptr, nullptr};
   bool stage_busy[STAGE_RING] = {false, false, false};
+  uint8_t* result = nullptr;  // pinned host, RESULT_BYTES: where small results land before the memcpy into the caller's memory
   int stage_next = 0;
   HostCtx* next = nullptr;
 };
@@ -74,6 +76,19 @@ struct StatTimer {   // adds the scope's wall time to a field of the calling thr
   explicit StatTimer(double& f) : field(f), t0(std::chrono::steady_clock::now()) {}
   ~StatTimer() { field += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
 };
+
+// A small result (a point, a few KiB) from device memory to the caller's PAGEABLE memory, through the context's
+// pinned result buffer: the only caller memory an entry point hands to the HIP runtime is a constant of <= 192 bytes
+// (a root of unity, a base point: copied through the runtime's own staging, never pinned).  (The runtime may pin
+// — register with the kernel driver — pageable ranges it is given and keep the registration; when such a range is
+// later unmapped or recycled by the caller's allocator, the driver's MMU notifier evicts ALL GPU queues of the
+// process for 10-30 ms.  That is what the alternating 6 / 25 ms calls of tools/host_path.py were: the harness's own
+// torch.from_numpy(large temporary).cuda() uploads, DESIGN.md section 6.  Large transfers already went through the
+// staging ring; this closes the last pageable destinations.)
+// small_d2h_begin queues the copy into the result buffer at `slot_off`; small_d2h_end, after the stream has been
+// waited for, copies it out.
+int small_d2h_begin(HostCtx* c, size_t slot_off, const void* d_src, size_t bytes, hipStream_t st);
+void small_d2h_end(HostCtx* c, size_t slot_off, void* h_dst, size_t bytes);
 
 struct CtxGuard {  // release on scope exit
   HostCtx* c = nullptr;

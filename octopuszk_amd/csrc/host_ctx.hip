@@ -144,6 +144,7 @@ void ctx_destroy(HostCtx* c) {
     if (c->stage[i]) hipHostFree(c->stage[i]);
     if (c->stage_free[i]) hipEventDestroy(c->stage_free[i]);
   }
+  if (c->result) hipHostFree(c->result);
   if (c->arena) hipFree(c->arena);
   delete c;
 }
@@ -181,6 +182,7 @@ int ctx_acquire(int task_id, HostCtx** out) {
       if (e == hipSuccess) e = hipHostMalloc((void**)&c->stage[i], STAGE_BYTES, hipHostMallocDefault);
       if (e == hipSuccess) e = hipEventCreateWithFlags(&c->stage_free[i], hipEventDisableTiming);
     }
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->result, RESULT_BYTES, hipHostMallocDefault);
     if (e != hipSuccess) {
       ctx_destroy(c);
       return fail(e == hipErrorOutOfMemory ? OZK_E_NOMEM : OZK_E_NO_DEVICE, "creating a host context failed: %s",
@@ -230,6 +232,14 @@ static int stage_wait(HostCtx* c, int b) {
   return OZK_OK;
 }
 
+int small_d2h_begin(HostCtx* c, size_t slot_off, const void* d_src, size_t bytes, hipStream_t st) {
+  if (slot_off + bytes > RESULT_BYTES) return fail(OZK_E_INTERNAL, "result of %zu bytes does not fit the pinned result buffer", bytes);
+  StatTimer tq(host_call_stats().enqueue_ms);
+  OZK_HIP(hipMemcpyAsync(c->result + slot_off, d_src, bytes, hipMemcpyDeviceToHost, st));
+  return OZK_OK;
+}
+void small_d2h_end(HostCtx* c, size_t slot_off, void* h_dst, size_t bytes) { memcpy(h_dst, c->result + slot_off, bytes); }
+
 int staged_h2d(HostCtx* c, void* d_dst, const void* h_src, size_t bytes, hipStream_t st) {
   size_t off = 0;
   while (off < bytes) {
@@ -244,8 +254,13 @@ int staged_h2d(HostCtx* c, void* d_dst, const void* h_src, size_t bytes, hipStre
       parallel_memcpy(c->stage[b], (const uint8_t*)h_src + off, len);
     }
     StatTimer tq(host_call_stats().enqueue_ms);
+    const auto te0 = std::chrono::steady_clock::now();
     OZK_HIP(hipMemcpyAsync((uint8_t*)d_dst + off, c->stage[b], len, hipMemcpyHostToDevice, st));
     OZK_HIP(hipEventRecord(c->stage_free[b], st));
+    if (env_int("OZK_HOST_TRACE", 0) >= 2)   // absolute CLOCK_MONOTONIC ns: comparable with rocprofv3's timestamps
+      fprintf(stderr, "[ozk] h2d chunk %zu B buffer %d stream %p: enqueue began %lld ns, returned %lld ns\n", len, b, (void*)st,
+              (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(te0.time_since_epoch()).count(),
+              (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count());
     c->stage_busy[b] = true;
     off += len;
   }
@@ -264,8 +279,10 @@ int staged_d2h_gated(HostCtx* c, void* h_dst, const void* d_src, size_t bytes, h
       if (rc) return rc;
     }
     StatTimer tm(host_call_stats().sync_ms);
-    OZK_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, st));
+    int rc = small_d2h_begin(c, 0, d_src, bytes, st);
+    if (rc) return rc;
     OZK_HIP(hipStreamSynchronize(st));
+    small_d2h_end(c, 0, h_dst, bytes);
     return OZK_OK;
   }
   const size_t nchunks = (bytes + STAGE_BYTES - 1) / STAGE_BYTES;

@@ -108,6 +108,7 @@ void bases_free(BasesHandle* h) {  // nobody else can reach h any more
   hipFree(h->d_prepared);
   hipFree(h->d_scalars);
   hipFree(h->d_out);
+  if (h->h_out) hipHostFree(h->h_out);
   hipFree(h->d_ws);
   if (h->st) hipStreamDestroy(h->st);
   pthread_mutex_destroy(&h->mu);
@@ -343,10 +344,12 @@ int ozk_var_double_msm_host(const uint8_t* bases_g1, const uint8_t* bases_g2, co
     if ((rc = host_sliced_msm<G2Cfg>(c, bases_g2, nullptr, n, K, per, d_b2, d_sc, d_w2, d_out + 256, c->slice_ev + K,
                                      c->st[1], up)))
       return rc;
-    OZK_HIP(hipMemcpyAsync(out, d_out, 192, hipMemcpyDeviceToHost, c->st[0]));
-    OZK_HIP(hipMemcpyAsync(out + 192, d_out + 256, 384, hipMemcpyDeviceToHost, c->st[1]));
+    if ((rc = small_d2h_begin(c, 0, d_out, 192, c->st[0]))) return rc;
+    if ((rc = small_d2h_begin(c, 1024, d_out + 256, 384, c->st[1]))) return rc;
     OZK_HIP(hipStreamSynchronize(c->st[0]));
     OZK_HIP(hipStreamSynchronize(c->st[1]));
+    small_d2h_end(c, 0, out, 192);
+    small_d2h_end(c, 1024, out + 192, 384);
     return OZK_OK;
   }
   const size_t b1 = (size_t)n * 96, b2 = (size_t)n * 192, sc = (size_t)n * 32;
@@ -368,10 +371,12 @@ int ozk_var_double_msm_host(const uint8_t* bases_g1, const uint8_t* bases_g2, co
   OZK_HIP(hipStreamWaitEvent(s2, c->ev[0], 0));
   if ((rc = staged_h2d(c, d_b2, bases_g2, b2, s2))) return rc;
   if ((rc = var_msm_dev<G2Cfg>(d_b2, d_sc, n, d_out + 256, d_w2, w2, s2))) return rc;
-  OZK_HIP(hipMemcpyAsync(out, d_out, 192, hipMemcpyDeviceToHost, s1));
-  OZK_HIP(hipMemcpyAsync(out + 192, d_out + 256, 384, hipMemcpyDeviceToHost, s2));
+  if ((rc = small_d2h_begin(c, 0, d_out, 192, s1))) return rc;
+  if ((rc = small_d2h_begin(c, 1024, d_out + 256, 384, s2))) return rc;
   OZK_HIP(hipStreamSynchronize(s1));
   OZK_HIP(hipStreamSynchronize(s2));
+  small_d2h_end(c, 0, out, 192);
+  small_d2h_end(c, 1024, out + 192, 384);
   return OZK_OK;
 }
 
@@ -435,11 +440,15 @@ int ozk_var_msm_sharded_host(const uint8_t* bases, const uint8_t* scalars, int32
   if (rc) return rc;
   HostCtx* c = g.c;
   if ((rc = ctx_reserve(c, pad256(partial.size()) + 1024))) return rc;
-  OZK_HIP(hipMemcpyAsync(c->arena, partial.data(), partial.size(), hipMemcpyHostToDevice, c->st[0]));
+  // (through the pinned result buffer both ways: host_ctx.h, small_d2h_begin)
+  if (partial.size() + 1024 > RESULT_BYTES) return fail(OZK_E_INTERNAL, "partials do not fit the pinned result buffer");
+  memcpy(c->result + 1024, partial.data(), partial.size());
+  OZK_HIP(hipMemcpyAsync(c->arena, c->result + 1024, partial.size(), hipMemcpyHostToDevice, c->st[0]));
   uint8_t* d_out = c->arena + pad256(partial.size());
   if ((rc = ozk_points_sum_dev(c->arena, k, type, d_out, c->st[0]))) return rc;
-  OZK_HIP(hipMemcpyAsync(out, d_out, ob, hipMemcpyDeviceToHost, c->st[0]));
+  if ((rc = small_d2h_begin(c, 0, d_out, ob, c->st[0]))) return rc;
   OZK_HIP(hipStreamSynchronize(c->st[0]));
+  small_d2h_end(c, 0, out, ob);
   return OZK_OK;
 }
 

@@ -711,6 +711,7 @@ struct BasesHandle {
   int device, n, type;
   hipStream_t st;
   uint8_t *d_prepared, *d_scalars, *d_out, *d_ws;
+  uint8_t* h_out;  // pinned host, 1 KiB: the result lands here (host_ctx.h, small_d2h_begin)
   size_t ws_bytes;
   pthread_mutex_t mu;
 };
@@ -733,6 +734,7 @@ int bases_create(const uint8_t* bases, int n, int type, int task_id, BasesHandle
   if (e == hipSuccess) e = hipMalloc((void**)&h->d_prepared, pb);
   if (e == hipSuccess) e = hipMalloc((void**)&h->d_scalars, (size_t)n * 32 + 256);
   if (e == hipSuccess) e = hipMalloc((void**)&h->d_out, 1024);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_out, 1024, hipHostMallocDefault);
   if (e == hipSuccess) e = hipMalloc((void**)&h->d_ws, h->ws_bytes);
   if (e == hipSuccess) e = hipMalloc((void**)&d_wire, wire);
   rc = OZK_OK;
@@ -749,6 +751,7 @@ int bases_create(const uint8_t* bases, int n, int type, int task_id, BasesHandle
     if (h->d_prepared) hipFree(h->d_prepared);
     if (h->d_scalars) hipFree(h->d_scalars);
     if (h->d_out) hipFree(h->d_out);
+    if (h->h_out) hipHostFree(h->h_out);
     if (h->d_ws) hipFree(h->d_ws);
     if (h->st) hipStreamDestroy(h->st);
     free(h);
@@ -781,8 +784,9 @@ int bases_msm(BasesHandle* h, const uint8_t* scalars, uint8_t* out) {
     if (rc || e != hipSuccess) break;
     rc = var_msm_dev<CV>(nullptr, h->d_scalars, h->n, h->d_out, h->d_ws, h->ws_bytes, h->st, h->d_prepared);
     if (rc) break;
-    if ((e = hipMemcpyAsync(out, h->d_out, out_bytes, hipMemcpyDeviceToHost, h->st)) != hipSuccess) break;
+    if ((e = hipMemcpyAsync(h->h_out, h->d_out, out_bytes, hipMemcpyDeviceToHost, h->st)) != hipSuccess) break;
     e = hipStreamSynchronize(h->st);
+    if (e == hipSuccess) memcpy(out, h->h_out, out_bytes);
   } while (0);
   pthread_mutex_unlock(&h->mu);
   if (rc) return rc;

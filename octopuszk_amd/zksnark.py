@@ -77,8 +77,17 @@ def _le32(values) -> bytes:
     return b"".join(int(v).to_bytes(32, "little") for v in values)
 
 
+def _upload(a: np.ndarray) -> torch.Tensor:
+    """A host TEMPORARY to the device.  Large ones go through pinned memory: handed a pageable range, the HIP runtime
+    registers it with the kernel driver, and when the freed range is later recycled and unmapped the driver evicts all
+    GPU queues of the process for 10-30 ms — a stall that would land in some later proof."""
+    a = np.ascontiguousarray(a)
+    t = torch.from_numpy(a if a.flags.writeable else a.copy())
+    return (t.pin_memory() if t.numel() * t.element_size() >= (1 << 20) else t).cuda()
+
+
 def _dev_bytes(b: bytes) -> torch.Tensor:
-    return torch.from_numpy(np.frombuffer(b, dtype=np.uint8).copy()).cuda()
+    return _upload(np.frombuffer(b, dtype=np.uint8))
 
 
 def _ptr(t):
@@ -224,10 +233,10 @@ class R1CSDevice:
             ptr = np.concatenate((ptr, np.full(m + 1 - len(ptr), ptr[-1], dtype=np.int64)))
             assert len(ptr) == m + 1 and ptr[-1] == len(idx) < 1 << 32
             long_rows = np.nonzero(np.diff(ptr) > 64)[0].astype(np.uint32)
-            d = dict(ptr=torch.from_numpy(ptr.astype(np.uint32).view(np.uint8).copy()).cuda(),
-                     idx=torch.from_numpy(idx.astype(np.uint32).view(np.uint8).copy()).cuda(),
+            d = dict(ptr=_upload(ptr.astype(np.uint32).view(np.uint8)),
+                     idx=_upload(idx.astype(np.uint32).view(np.uint8)),
                      coeff=None if val is None else _dev_bytes(_le32(int(v) % FR for v in val)),
-                     long=torch.from_numpy(long_rows.view(np.uint8).copy()).cuda() if len(long_rows) else None,
+                     long=_upload(long_rows.view(np.uint8)) if len(long_rows) else None,
                      n_long=len(long_rows))
             self.mats.append(d)
         self.out = [torch.empty(m * 32, dtype=torch.uint8, device="cuda") for _ in range(3)]
@@ -356,10 +365,10 @@ class R1CSTransposedDevice:
             assert len(ptr) == nv + 1 and ptr[-1] == len(idx) < 1 << 32
             long_rows = np.nonzero(np.diff(ptr) > 64)[0].astype(np.uint32)
             self.mats.append(dict(
-                ptr=torch.from_numpy(ptr.astype(np.uint32).view(np.uint8).copy()).cuda(),
-                idx=torch.from_numpy(idx.astype(np.uint32).view(np.uint8).copy()).cuda(),
+                ptr=_upload(ptr.astype(np.uint32).view(np.uint8)),
+                idx=_upload(idx.astype(np.uint32).view(np.uint8)),
                 coeff=None if val is None else _dev_bytes(_le32(int(v) % FR for v in val[order])),
-                long=torch.from_numpy(long_rows.view(np.uint8).copy()).cuda() if len(long_rows) else None,
+                long=_upload(long_rows.view(np.uint8)) if len(long_rows) else None,
                 n_long=len(long_rows)))
         self.ws_bytes = int(_lib.load().ozk_r1cs_evaluate_workspace_bytes(max(d["n_long"] for d in self.mats)))
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device="cuda")

@@ -24,6 +24,18 @@ gc.disable()
 L = ozk.load()
 
 
+def to_device(a):
+    """numpy -> device through PINNED memory.  torch.from_numpy(x).cuda() on a large pageable temporary makes the HIP
+    runtime register that range with the kernel driver; once the temporary is freed and the range recycled by the
+    fresh input buffers of later calls, every unmap of it evicts all GPU queues of the process for 10-30 ms — the
+    alternating 6 / 25 ms calls this script used to show for the double MSM.  --pageable-uploads
+    brings them back."""
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if "--pageable-uploads" in sys.argv:
+        return t.cuda()
+    return t.pin_memory().cuda()
+
+
 def vp(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
@@ -61,7 +73,8 @@ def run(name, fn, make_inputs, reps, moved_mib, dev_ms=None):
 
 
 def main():
-    logn = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+    logn = int(pos[0]) if pos else 20
     n = 1 << logn
     print("device:", torch.cuda.get_device_name(0), " n = 2^%d" % logn, flush=True)
     g1 = bytes(dev.gen_g1_bases(n, seed=2).cpu().numpy())
@@ -69,7 +82,7 @@ def main():
     sc = scalars(n, 1)
     out = np.zeros(576, dtype=np.uint8)
     # device-resident reference
-    d_b, d_s = torch.from_numpy(g1.copy()).cuda(), torch.from_numpy(sc.reshape(-1)).cuda()
+    d_b, d_s = to_device(g1.copy()), to_device(sc.reshape(-1))
     ws = dev.VarMsmWorkspace(n, 1)
     ws.run(d_b, d_s)
     torch.cuda.synchronize()
@@ -100,11 +113,12 @@ def main():
     ks = scalars(m, 9)
     ks[:, 8:] = 0
     st = int(torch.cuda.current_stream().cuda_stream)
-    base2 = torch.from_numpy(np.frombuffer(o.g2_to_wire(o.G2.one), dtype=np.uint8).copy()).cuda()
+    base2 = to_device(np.frombuffer(o.g2_to_wire(o.G2.one), dtype=np.uint8).copy())
     g2d = torch.empty(m * 192, dtype=torch.uint8, device="cuda")
     wsb = int(L.ozk_fixed_batch_msm_workspace_bytes(16, 16, m, 2))
     wsf = torch.empty(wsb, dtype=torch.uint8, device="cuda")
-    ozk.check(L.ozk_fixed_batch_msm_compact_dev(16, 16, m, int(base2.data_ptr()), int(torch.from_numpy(ks.reshape(-1)).cuda().data_ptr()),
+    d_ks = to_device(ks.reshape(-1))
+    ozk.check(L.ozk_fixed_batch_msm_compact_dev(16, 16, m, int(base2.data_ptr()), int(d_ks.data_ptr()),
                                                 2, int(g2d.data_ptr()), int(wsf.data_ptr()), wsb, st))
     torch.cuda.synchronize()
     g2 = g2d.cpu().numpy()
