@@ -9,7 +9,12 @@ namespace ozk {
 // A handful of helper threads that do nothing but memcpy between caller memory and the pinned ring: one
 // core moves ~12 GB/s, the PCIe link 57 GB/s.  Started on first use; they sleep on a condition variable.
 namespace {
-constexpr int COPY_HELPERS = 3;  // + the calling thread
+constexpr int COPY_HELPERS = 3;  // + the calling thread (default; OZK_COPY_HELPERS up to COPY_HELPERS_MAX)
+constexpr int COPY_HELPERS_MAX = 11;
+static int copy_helpers() {
+  static const int h = env_int("OZK_COPY_HELPERS", COPY_HELPERS);   // 0: the calling thread copies alone
+  return h < 0 ? 0 : (h > COPY_HELPERS_MAX ? COPY_HELPERS_MAX : h);
+}
 constexpr int COPY_QUEUE = 64;
 struct CopyTask {
   void* dst;
@@ -24,7 +29,7 @@ struct CopyPool {
   int head = 0, count = 0;
   bool started = false, failed = false, stop = false;
   int running = 0;
-  pthread_t th[COPY_HELPERS];
+  pthread_t th[COPY_HELPERS_MAX];
 };
 CopyPool g_copy;
 
@@ -56,7 +61,7 @@ void copy_start_locked() {
   if (g_copy.started || g_copy.failed) return;
   g_copy.stop = false;
   g_copy.running = 0;
-  for (int i = 0; i < COPY_HELPERS; i++) {
+  for (int i = 0; i < copy_helpers(); i++) {
     if (pthread_create(&g_copy.th[i], nullptr, copy_worker, nullptr) != 0) {
       g_copy.failed = true;  // (already running helpers keep working; the caller copies the rest itself)
       break;
@@ -82,12 +87,12 @@ void copy_shutdown() {
   pthread_mutex_unlock(&g_copy.mu);
 }
 void parallel_memcpy(void* dst, const void* src, size_t len) {
-  static const int helpers = env_int("OZK_COPY_HELPERS", COPY_HELPERS);   // 0: the calling thread copies alone
+  const int helpers = copy_helpers();
   if (len < ((size_t)1 << 20) || helpers <= 0) {
     memcpy(dst, src, len);
     return;
   }
-  const int parts = (helpers < COPY_HELPERS ? helpers : COPY_HELPERS) + 1;
+  const int parts = helpers + 1;
   const size_t per = ((len + parts - 1) / parts + 63) & ~(size_t)63;
   std::atomic<int> pending(0);
   pthread_mutex_lock(&g_copy.mu);
