@@ -27,13 +27,11 @@
 namespace ozk {
 
 using FrP = FrParams;
-// Elements per workgroup tile: 2048 (72 KiB of LDS at 9 words each, two workgroups per CU) lets a pass do up
-// to 11 stages, so 2^22 is TWO passes over HBM instead of three (round 1: 1024-element tiles, 8 stages per
-// pass, 0.77 ms at 2^22 of which ~70 us per pass is the tile's trip through HBM).  512 threads per workgroup keep two
-// butterflies per thread and stage and four waves per SIMD.
-constexpr int FFT_TILE_BIG = 2048, FFT_TILE_SMALL = 1024;
+// Elements per workgroup tile: 1024 (36 KiB of LDS at 9 words each; 256 threads, four elements per thread and stage
+// pair), at most 8 stages per pass: 2^22 is three passes.  A 2048-element tile (two passes of 11 stages) and a
+// 512-element one were carried as options through round 3 and measured slower (0.62-0.67 / 0.57 ms against 0.545).
+constexpr int FFT_TILE_SMALL = 1024;
 constexpr int FFT_THREADS = 256;
-constexpr int FFT_MAXK = 11;     // stages per pass (log2 of the biggest tile)
 constexpr int TW_LO = 2048;
 
 // ---- twiddle table -------------------------------------------------------
@@ -154,12 +152,15 @@ __device__ __forceinline__ Fe<FrP, 96> gunpack(const uint4& v0, const uint4& v1)
   const u32 w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
   return Fe<FrP, 96>(unpack<FrP, 85>(w));   // FIRST: arbitrary 256-bit wire value (85); later passes: stored < 4p
 }
-template <bool FIRST, int TILE, int B>
-__device__ __forceinline__ void gstore(const PassArgs& a, int T, int logT, u32 mid, u32 ul, const Fe<FrP, B>& v, bool last) {
+// LAST: 0 = a pass that is not the last (packed < 17 p / 16 to the workspace), 1 = the last pass (canonical, wire
+// format), 2 = the last pass with the output scaling.  A template parameter, not a flag: the kernels of the middle
+// passes do not carry the registers of the scaling product (the register count of a kernel is that of its worst path).
+template <bool FIRST, int TILE, int LAST, int B>
+__device__ __forceinline__ void gstore(const PassArgs& a, int T, int logT, u32 mid, u32 ul, const Fe<FrP, B>& v) {
   const u32 i = tile_index<FIRST>(a, blockIdx.x, T, logT, mid, ul);
   u32 o[8];
-  if (last) {
-    if (a.scale != nullptr) pack(canonical(mul(v, ElemTraits<Fe<FrP, 16>>::load(a.scale + (size_t)i * 8))), o);
+  if constexpr (LAST != 0) {
+    if constexpr (LAST == 2) pack(canonical(mul(v, ElemTraits<Fe<FrP, 16>>::load(a.scale + (size_t)i * 8))), o);
     else pack(canonical_q(v), o);
     uint4* dst = reinterpret_cast<uint4*>(a.out + (size_t)i * a.out_stride);
     dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
@@ -210,8 +211,8 @@ __device__ __forceinline__ auto sub_nc(const Fe<FrP, B1>& a, const Fe<FrP, B2>& 
 // stage Q + 1 pairs (., x10') with w2a and (., x11') with w2b (their `low` differs in bit Q - 1).
 // SRC_G: the four inputs come straight from global memory (the first pair of a pass, Q = 1);
 // DST_G: the four outputs go straight to global memory (the last pair) — two LDS round trips fewer per pass.
-template <bool FIRST, int Q, int BIN, int TILE, bool SRC_G, bool DST_G>
-__device__ __forceinline__ void fft_stage2(u32* lds, const PassArgs& a, int T, int logT, bool last) {
+template <bool FIRST, int Q, int BIN, int TILE, bool SRC_G, bool DST_G, int LAST>
+__device__ __forceinline__ void fft_stage2(u32* lds, const PassArgs& a, int T, int logT) {
   using TW = ElemTraits<Fe<FrP, 16>>;
   const u32 g = threadIdx.x;                         // TILE / 4 groups, one per thread
   // lane -> (ul, r): ul fastest, so that a wave's global accesses come in runs of T consecutive elements; the
@@ -270,10 +271,10 @@ __device__ __forceinline__ void fft_stage2(u32* lds, const PassArgs& a, int T, i
   const auto v = mul(w2b, b1);
   if constexpr (DST_G) {
     const Fe<FrP, BIN + 64> y00 = add(a0, u), y10 = sub(a0, u), y01 = add(a1, v), y11 = sub(a1, v);
-    gstore<FIRST, TILE>(a, T, logT, m00, ul, y00, last);
-    gstore<FIRST, TILE>(a, T, logT, m01, ul, y01, last);
-    gstore<FIRST, TILE>(a, T, logT, m10, ul, y10, last);
-    gstore<FIRST, TILE>(a, T, logT, m11, ul, y11, last);
+    gstore<FIRST, TILE, LAST>(a, T, logT, m00, ul, y00);
+    gstore<FIRST, TILE, LAST>(a, T, logT, m01, ul, y01);
+    gstore<FIRST, TILE, LAST>(a, T, logT, m10, ul, y10);
+    gstore<FIRST, TILE, LAST>(a, T, logT, m11, ul, y11);
   } else {
     const Fe<FrP, BIN + 64> y00 = add_nc(a0, u), y10 = sub_nc(a0, u), y01 = add_nc(a1, v), y11 = sub_nc(a1, v);
     lds_store<TILE>(lds, e00, y00);
@@ -309,16 +310,16 @@ __device__ __forceinline__ void fft_stage1_from_global(u32* lds, const PassArgs&
 }
 
 // stages Q .. K of a pass whose first stage(s) already ran from global memory: pairs, the last one to global
-template <bool FIRST, int Q, int BIN, int TILE>
-__device__ __forceinline__ void fft_pairs_to_global(u32* lds, const PassArgs& a, int T, int logT, bool last) {
+template <bool FIRST, int Q, int BIN, int TILE, int LAST>
+__device__ __forceinline__ void fft_pairs_to_global(u32* lds, const PassArgs& a, int T, int logT) {
   if constexpr ((2 << Q) <= TILE) {
     if (Q + 1 == a.K) {
-      fft_stage2<FIRST, Q, BIN, TILE, false, true>(lds, a, T, logT, last);
+      fft_stage2<FIRST, Q, BIN, TILE, false, true, LAST>(lds, a, T, logT);
       return;
     }
     if (Q + 1 < a.K) {
-      fft_stage2<FIRST, Q, BIN, TILE, false, false>(lds, a, T, logT, last);
-      fft_pairs_to_global<FIRST, Q + 2, BIN + 64, TILE>(lds, a, T, logT, last);
+      fft_stage2<FIRST, Q, BIN, TILE, false, false, LAST>(lds, a, T, logT);
+      fft_pairs_to_global<FIRST, Q + 2, BIN + 64, TILE, LAST>(lds, a, T, logT);
     }
   }
 }
@@ -330,7 +331,7 @@ __device__ __forceinline__ void fft_stages(u32* lds, const PassArgs& a, int T, i
   if (Q > a.K) return;
   if constexpr (Q <= 2) {
     if (Q + 1 <= a.K) {
-      fft_stage2<FIRST, Q, BIN, TILE, false, false>(lds, a, T, logT, false);
+      fft_stage2<FIRST, Q, BIN, TILE, false, false, 0>(lds, a, T, logT);
       fft_stages<FIRST, Q + 2, BIN + 64, TILE>(lds, a, T, logT);
       return;
     }
@@ -338,8 +339,8 @@ __device__ __forceinline__ void fft_stages(u32* lds, const PassArgs& a, int T, i
   }
 }
 
-template <bool FIRST, int BEND, int TILE>
-__device__ __forceinline__ void fft_store_tile(u32* lds, const PassArgs& a, int T, int logT, bool last) {
+template <bool FIRST, int BEND, int TILE, int LAST>
+__device__ __forceinline__ void fft_store_tile(u32* lds, const PassArgs& a, int T, int logT) {
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const u32 e = threadIdx.x + (u32)k * (TILE / 4);
@@ -347,31 +348,17 @@ __device__ __forceinline__ void fft_store_tile(u32* lds, const PassArgs& a, int 
     // first pass consecutive mid (contiguous outputs) — see tile_index
     const u32 ul = FIRST ? (e >> (31 - __clz(TILE / T))) : (e & (u32)(T - 1));
     const u32 mid = FIRST ? (e & (u32)(TILE / T - 1)) : (e >> logT);
-    const u32 i = tile_index<FIRST>(a, blockIdx.x, T, logT, mid, ul);
     auto v = lds_load<BEND, TILE>(lds, mid * T + ul);
     fe_carry(v);   // (a pair leaves its outputs uncarried in LDS)
-    u32 o[8];
-    if (last) {
-      if (a.scale != nullptr) pack(canonical(mul(v, ElemTraits<Fe<FrP, 16>>::load(a.scale + (size_t)i * 8))), o);
-      else pack(canonical_q(v), o);
-      uint4* dst = reinterpret_cast<uint4*>(a.out + (size_t)i * a.out_stride);
-      dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
-      dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
-      if (a.out_stride == 16) {
-        dst[2] = make_uint4(0, 0, 0, 0);
-        dst[3] = make_uint4(0, 0, 0, 0);
-      }
-    } else {
-      pack(reduce_q(v), o);
-      uint4* dst = reinterpret_cast<uint4*>(a.out + (size_t)i * 8);
-      dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
-      dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
-    }
+    gstore<FIRST, TILE, LAST>(a, T, logT, mid, ul, v);
   }
 }
 
-template <bool FIRST, int TILE>
-__global__ void __launch_bounds__(TILE / 4) k_fft_pass(PassArgs a, int last) {
+// KODD: the pass has an odd number of stages (it opens with one stage from global memory instead of a pair).  A
+// template parameter because the two paths differ by 60 registers: compiled into one kernel, the odd path's 155 set
+// the occupancy of both (3 waves per SIMD instead of 5).
+template <bool FIRST, int TILE, int LAST, bool KODD>
+__global__ void __launch_bounds__(TILE / 4) k_fft_pass(PassArgs a) {
   extern __shared__ __attribute__((aligned(16))) u32 lds[];  // 9 * TILE words
   const int M = 1 << a.K;
   const int T = TILE / M;
@@ -381,15 +368,16 @@ __global__ void __launch_bounds__(TILE / 4) k_fft_pass(PassArgs a, int last) {
   if (a.K >= 3) {
     // the first stage(s) read the tile from global memory, the last pair writes it back: LDS is only the
     // exchange between the stage pairs in between (three round trips instead of five for 8 stages)
-    if (a.K & 1) {
+    if constexpr (KODD) {
       fft_stage1_from_global<FIRST, TILE>(lds, a, T, logT);
-      fft_pairs_to_global<FIRST, 2, B0 + 32, TILE>(lds, a, T, logT, last != 0);
+      fft_pairs_to_global<FIRST, 2, B0 + 32, TILE, LAST>(lds, a, T, logT);
     } else {
-      fft_stage2<FIRST, 1, B0, TILE, true, false>(lds, a, T, logT, false);
-      fft_pairs_to_global<FIRST, 3, B0 + 64, TILE>(lds, a, T, logT, last != 0);
+      fft_stage2<FIRST, 1, B0, TILE, true, false, LAST>(lds, a, T, logT);
+      fft_pairs_to_global<FIRST, 3, B0 + 64, TILE, LAST>(lds, a, T, logT);
     }
     return;
   }
+  if constexpr (KODD) return;   // (short passes are launched with KODD = false)
   // short passes (tiny transforms): tile in, stages through LDS, tile out
   {
     uint4 v0[4], v1[4];
@@ -406,7 +394,7 @@ __global__ void __launch_bounds__(TILE / 4) k_fft_pass(PassArgs a, int last) {
   }
   block_sync();
   fft_stages<FIRST, 1, B0, TILE>(lds, a, T, logT);
-  fft_store_tile<FIRST, B0 + 32 * LOGT, TILE>(lds, a, T, logT, last != 0);
+  fft_store_tile<FIRST, B0 + 32 * LOGT, TILE, LAST>(lds, a, T, logT);
 }
 
 // n == 1 or tiny n (< FFT_TILE): one workgroup, direct global-memory version of the same
@@ -495,37 +483,37 @@ static int fft_core(const u32* d_in, int n, const u32* tw, u32* d_out, int out_s
     OZK_HIP(hipGetLastError());
     return OZK_OK;
   }
-  // Passes of at most 8 stages (11 with the 2048-element tile), the stages spread evenly, the larger share
-  // first (the first pass reads bit-reversed and writes a contiguous tile whatever K is; a later pass with K
-  // stages touches HBM in runs of TILE / 2^K elements).  OZK_FFT_TILE = 512 | 1024 | 2048 selects the tile.
-  int tile = env_int("OZK_FFT_TILE", FFT_TILE_SMALL);
-  if (tile != 512 && tile != 1024 && tile != 2048) tile = FFT_TILE_SMALL;
-  if (tile > n) tile = FFT_TILE_SMALL;
-  int maxk = env_int("OZK_FFT_MAXK", tile == 2048 ? 11 : 8);
-  if (maxk < 2) maxk = 2;
-  if (maxk > (tile == 2048 ? 11 : (tile == 1024 ? 10 : 9))) maxk = tile == 2048 ? 11 : (tile == 1024 ? 10 : 9);
-  const int npass = (logn + maxk - 1) / maxk;
+  // Passes of at most 8 stages.  Every pass AFTER the first gets an EVEN number of stages (its kernel then opens with
+  // a stage pair: 93 registers, 4 waves per SIMD with the tile's 36 KiB of LDS; the odd form needs 150 and runs 3), so
+  // the first pass — whose kernel is lean either way (79) — takes the parity of log2 n; within that, the larger shares
+  // first (a later pass with K stages touches HBM in runs of TILE / 2^K elements).  2^22: 8 + 8 + 6; 2^21: 7 + 8 + 6.
+  // OZK_FFT_PLAN=0: the even split of rounds 1-2 (2^22: 8 + 7 + 7).
+  constexpr int tile = FFT_TILE_SMALL;
+  int maxk = env_int("OZK_FFT_MAXK", 8);
+  if (maxk < 3) maxk = 3;
+  if (maxk > 10) maxk = 10;
+  int npass = (logn + maxk - 1) / maxk;
+  int plan[16], planned = 0;
+  if (env_int("OZK_FFT_PLAN", 1) && npass > 1) {
+    const int evenmax = maxk & ~1;
+    for (int np = npass; np <= npass + 1 && !planned; np++)
+      for (int k0 = (logn < maxk ? logn : maxk); k0 >= 3 && !planned; k0--) {
+        const int rest = logn - k0, parts = np - 1;
+        if (rest <= 0 || (rest & 1) || rest < 4 * parts || rest > evenmax * parts) continue;
+        plan[0] = k0;
+        const int units = rest / 2;   // pairs of stages, spread over the later passes, larger shares first
+        for (int i = 0; i < parts; i++) plan[1 + i] = 2 * (units / parts + (i < units % parts ? 1 : 0));
+        planned = np;
+      }
+    if (planned) npass = planned;
+  }
   int sbits = 0, cur = 0;
   u32* bufs[2] = {buf0, buf1};
   const u32* src = d_in;
   const size_t lds_bytes = (size_t)9 * tile * 4;
-  if (tile == 2048) {
-    static bool attr_set = false;  // (idempotent; a race only repeats it)
-    if (!attr_set) {
-      OZK_HIP(hipFuncSetAttribute((const void*)(k_fft_pass<true, 2048>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-      OZK_HIP(hipFuncSetAttribute((const void*)(k_fft_pass<false, 2048>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-      attr_set = true;
-    }
-  }
   for (int pass = 0; pass < npass; pass++) {
     const int left = logn - sbits, passes_left = npass - pass;
-    int K = (left + passes_left - 1) / passes_left;
-    // the first pass opens with a stage PAIR when its K is even, and that pair costs one product instead of four
-    // (fft_stage2, FIRST && Q == 1): give it the even share when the later passes can take the rest
-    if (pass == 0 && npass > 1 && (K & 1) && env_int("OZK_FFT_EVEN_FIRST", 1)) {
-      if (K + 1 <= maxk && left - (K + 1) >= 3 * (npass - 1)) K += 1;
-      else if (K - 1 >= 4 && left - (K - 1) <= (npass - 1) * maxk) K -= 1;
-    }
+    const int K = planned ? plan[pass] : (left + passes_left - 1) / passes_left;
     const bool last = pass == npass - 1;
     PassArgs a;
     a.in = src;
@@ -537,18 +525,25 @@ static int fft_core(const u32* d_in, int n, const u32* tw, u32* d_out, int out_s
     a.sbits = sbits;
     a.K = K;
     a.scale = last ? scale : nullptr;
-    const int tiles = n / tile, li = last ? 1 : 0;
-#define OZK_FFT_LAUNCH(TL)                                                                                          \
-  if (pass == 0)                                                                                                    \
-    hipLaunchKernelGGL((k_fft_pass<true, TL>), dim3(tiles), dim3(TL / 4), lds_bytes, st, a, li);                    \
-  else                                                                                                              \
-    hipLaunchKernelGGL((k_fft_pass<false, TL>), dim3(tiles), dim3(TL / 4), lds_bytes, st, a, li);
-    if (tile == 2048) {
-      OZK_FFT_LAUNCH(2048)
-    } else if (tile == 512) {
-      OZK_FFT_LAUNCH(512)
+    const int tiles = n / tile;
+    const int mode = !last ? 0 : (a.scale ? 2 : 1);
+#define OZK_FFT_LAUNCH(F, MODE)                                                                                          \
+  do {                                                                                                                   \
+    if (K >= 3 && (K & 1))                                                                                               \
+      hipLaunchKernelGGL((k_fft_pass<F, FFT_TILE_SMALL, MODE, true>), dim3(tiles), dim3(FFT_TILE_SMALL / 4), lds_bytes,  \
+                         st, a);                                                                                         \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((k_fft_pass<F, FFT_TILE_SMALL, MODE, false>), dim3(tiles), dim3(FFT_TILE_SMALL / 4), lds_bytes, \
+                         st, a);                                                                                         \
+  } while (0)
+    if (pass == 0) {
+      if (mode == 0) OZK_FFT_LAUNCH(true, 0);
+      else if (mode == 1) OZK_FFT_LAUNCH(true, 1);
+      else OZK_FFT_LAUNCH(true, 2);
     } else {
-      OZK_FFT_LAUNCH(1024)
+      if (mode == 0) OZK_FFT_LAUNCH(false, 0);
+      else if (mode == 1) OZK_FFT_LAUNCH(false, 1);
+      else OZK_FFT_LAUNCH(false, 2);
     }
 #undef OZK_FFT_LAUNCH
     src = a.out;
