@@ -243,6 +243,16 @@ int ozk_fixed_batch_msm_compact_dev(int32_t outerc, int32_t window_size, int32_t
                                     size_t workspace_bytes, void* stream);
 int ozk_fixed_batch_msm_compact_host(int32_t outerc, int32_t window_size, int32_t n, const uint8_t* base,
                                      const uint8_t* scalars, int32_t bn_type, int32_t task_id, uint8_t* out);
+/* Device-resident scalars and results, the base point given as HOST bytes (wire format, 96 / 192 B): the window
+ * table — what the reference's Java side computes once per key element (getWindowTable, FixedBaseMSM.java:71-99) and
+ * its native side rebuilds inside every call (algebra_msm_FixedBaseMSM.cu:851-992) — comes from a per-device cache
+ * keyed by the base, so the second and later batches over one generator skip the doubling chain and the table
+ * (0.65 / 2.1 ms of a 1.75 / 5.45 ms G1 / G2 call at 2^20).  The `*_host` entry points use the same cache.
+ * compact != 0: the 32-byte little-endian layout of ozk_fixed_batch_msm_compact_dev.  Workspace:
+ * ozk_fixed_batch_msm_workspace_bytes.  ozk_host_cache_release() frees the cached tables. */
+int ozk_fixed_batch_msm_base_dev(int32_t outerc, int32_t window_size, int32_t n, const uint8_t* base_host,
+                                 const void* d_scalars, int32_t bn_type, void* d_out, int32_t compact,
+                                 void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------- radix-2 FFT over Fr -----------------------------------
  * replaces Java_algebra_fft_FFTAuxiliary_serialRadix2FFTNativeHelper

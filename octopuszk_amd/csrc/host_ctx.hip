@@ -340,6 +340,7 @@ int staged_d2h_gated(HostCtx* c, void* h_dst, const void* d_src, size_t bytes, h
 
 namespace ozk {
 void fft_plan_cache_release();   // fft.hip
+void fb_table_cache_release();   // msm_fixed.hip
 }
 
 namespace {
@@ -368,6 +369,7 @@ extern "C" int ozk_host_cache_release(void) {
   using namespace ozk;
   copy_shutdown();
   fft_plan_cache_release();
+  fb_table_cache_release();
   pthread_mutex_lock(&g_pool_mu);
   for (int d = 0; d < MAX_DEVICES; d++) {
     HostCtx* c = g_free[d];

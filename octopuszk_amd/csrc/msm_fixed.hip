@@ -24,6 +24,10 @@
 //                 one lane, 1.2 ms for G1 and 5 ms for G2) and the table
 //   k_fb_norm     per lane a batch of results: one shared inversion (Montgomery's trick),
 //                 big-endian stores
+#include <algorithm>
+#include <new>
+#include <vector>
+
 #include "fq2.cuh"
 #include "glv.cuh"
 #include "msm_var.cuh"  // RunAccLds: the LDS-resident XYZZ accumulator (G2)
@@ -350,7 +354,7 @@ __global__ void __launch_bounds__(256) k_field_mul(const u32* __restrict__ in, i
 }
 
 struct FbLayout {
-  u32 *D, *table, *aff, *aff_phi, *jac;
+  u32 *D, *table, *aff, *aff_phi, *jac, *base;   // base: 256 B for a copy of the base point
   size_t bytes;
 };
 template <class CV>
@@ -363,7 +367,7 @@ static FbLayout fb_layout(int outerc, int ws, int n, void* wsp, size_t wsb) {
   L.aff = b.take<u32>(((size_t)outerc << ws) * IO::AFF_WORDS);  // the table again, affine (GLV form) ...
   L.aff_phi = b.take<u32>(((size_t)outerc << ws) * IO::AFF_WORDS);  // ... and its image under the endomorphism
   L.jac = b.take<u32>((size_t)n * IO::JAC_WORDS);
-  b.take<u32>(64);
+  L.base = b.take<u32>(64);
   L.bytes = b.off;
   return L;
 }
@@ -381,13 +385,11 @@ static int fb_check_args(int outerc, int ws, int n) {
 struct FbPlan {
   bool glv, affine;
   int wt, oc;   // table window size / windows actually used
+  const u32 *aff = nullptr, *aff_phi = nullptr;   // affine table and its image under the endomorphism; null: the
+                                                  // copies in the call's workspace (FbLayout)
 };
-template <class CV>
-static int fb_table(int outerc, int ws, int n, const void* d_base, void* wsp, size_t wsb, hipStream_t st, FbPlan* plan) {
-  using IO = CurveIO<CV>;
-  const FbLayout L = fb_layout<CV>(outerc, ws, n, wsp, wsb);
-  if (L.bytes > wsb) return fail(OZK_E_INVALID, "workspace too small: need %zu bytes, got %zu", L.bytes, wsb);
-  const int TB = 256;
+// form of the table for a call of n scalars (no device work)
+static FbPlan fb_choose(int outerc, int ws, int n) {
   // GLV form when the caller's windows cover a whole Fr scalar (they always do in the reference:
   // outerc = ceil(scalarSize / windowSize), FixedBaseMSM.java:71-99); the plain form otherwise
   const bool glv = env_int("OZK_MSM_GLV", 1) != 0 && (long long)outerc * ws >= 254;
@@ -407,7 +409,23 @@ static int fb_table(int outerc, int ws, int n, const void* d_base, void* wsp, si
     wt = env_int("OZK_FB_WS", wt);
     if (wt < 1 || wt > ws) wt = ws;
   }
-  const int oc = glv ? (128 + wt - 1) / wt : outerc;
+  FbPlan fp;
+  fp.glv = glv;
+  fp.affine = glv && env_int("OZK_FB_AFFINE", 1) != 0;
+  fp.wt = wt;
+  fp.oc = glv ? (128 + wt - 1) / wt : outerc;
+  return fp;
+}
+// builds the table of `fp` from the base point at d_base; the Jacobian table and the doubling chain live in the call's
+// workspace, the affine copies go to (aff, aff_phi) when given (a cached table), else into the workspace as well
+template <class CV>
+static int fb_build(const FbPlan& fp, int outerc, int ws, int n, const void* d_base, void* wsp, size_t wsb, hipStream_t st,
+                    u32* aff = nullptr, u32* aff_phi = nullptr) {
+  using IO = CurveIO<CV>;
+  const FbLayout L = fb_layout<CV>(outerc, ws, n, wsp, wsb);
+  if (L.bytes > wsb) return fail(OZK_E_INVALID, "workspace too small: need %zu bytes, got %zu", L.bytes, wsb);
+  const int TB = 256;
+  const int wt = fp.wt, oc = fp.oc;
   hipLaunchKernelGGL((k_fb_chain<CV>), dim3(1), dim3(64), 0, st, (const u32*)d_base, oc * wt, L.D);
   // entry 0 of every window is infinity: clear those records (all-zero Jacobian has Z = 0)
   OZK_HIP(hipMemset2DAsync(L.table, ((size_t)1 << wt) * IO::JAC_WORDS * 4, 0, IO::JAC_WORDS * 4, oc, st));
@@ -415,18 +433,19 @@ static int fb_table(int outerc, int ws, int n, const void* d_base, void* wsp, si
     const int tot = oc << k;
     hipLaunchKernelGGL((k_fb_level<CV>), dim3((tot + TB - 1) / TB), dim3(TB), 0, st, L.table, L.D, oc, wt, k);
   }
-  plan->glv = glv;
-  plan->affine = glv && env_int("OZK_FB_AFFINE", 1) != 0;
-  plan->wt = wt;
-  plan->oc = oc;
-  if (plan->affine) {
+  if (fp.affine) {
     const int entries = oc << wt;
     const int tl = (entries + FB_BATCH - 1) / FB_BATCH;
-    hipLaunchKernelGGL((k_fb_table_affine<CV>), dim3((tl + TB - 1) / TB), dim3(TB), 0, st, L.table, entries, L.aff,
-                       L.aff_phi);
+    hipLaunchKernelGGL((k_fb_table_affine<CV>), dim3((tl + TB - 1) / TB), dim3(TB), 0, st, L.table, entries,
+                       aff ? aff : L.aff, aff_phi ? aff_phi : L.aff_phi);
   }
   OZK_HIP(hipGetLastError());
   return OZK_OK;
+}
+template <class CV>
+static int fb_table(int outerc, int ws, int n, const void* d_base, void* wsp, size_t wsb, hipStream_t st, FbPlan* plan) {
+  *plan = fb_choose(outerc, ws, n);
+  return fb_build<CV>(*plan, outerc, ws, n, d_base, wsp, wsb, st);
 }
 
 // scalars [lo, lo + cnt) of the call's n: d_scalars / d_out point at element 0
@@ -443,8 +462,8 @@ static int fb_apply(const FbPlan& fp, int outerc, int ws, int n, int lo, int cnt
     if (acc_lds > 65536)
       OZK_HIP(hipFuncSetAttribute((const void*)(k_fb_main_glv_affine<CV>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)acc_lds));
-    hipLaunchKernelGGL((k_fb_main_glv_affine<CV>), dim3((cnt + TB - 1) / TB), dim3(TB), acc_lds, st, sc, L.aff,
-                       L.aff_phi, cnt, fp.oc, fp.wt, jac);
+    hipLaunchKernelGGL((k_fb_main_glv_affine<CV>), dim3((cnt + TB - 1) / TB), dim3(TB), acc_lds, st, sc,
+                       fp.aff ? fp.aff : L.aff, fp.aff_phi ? fp.aff_phi : L.aff_phi, cnt, fp.oc, fp.wt, jac);
   } else if (fp.glv)
     hipLaunchKernelGGL((k_fb_main_glv<CV>), dim3((cnt + TB - 1) / TB), dim3(TB), 0, st, sc, L.table, cnt, fp.oc, fp.wt,
                        jac);
@@ -464,6 +483,170 @@ static int fixed_batch_dev(int outerc, int ws, int n, const void* d_base, const 
   int rc = fb_table<CV>(outerc, ws, n, d_base, wsp, wsb, st, &fp);
   if (rc) return rc;
   return fb_apply<CV>(fp, outerc, ws, n, 0, n, d_scalars, d_out, out_stride_words, wsp, wsb, st, compact);
+}
+
+// ---- table cache ------------------------------------------------------------------------------
+// The window table depends only on (base, windowSize, outerc) and the size class of the call; the reference's Java
+// side computes it once per key element (getWindowTable, FixedBaseMSM.java:71-99) and its native side rebuilds it
+// inside every call (FixedBaseMSM.cu:851-992) — as this library did through round 3: doubling chain + levels +
+// batched normalisation = 0.65 ms (G1) / 2.1 ms (G2) of a 1.75 / 5.45 ms call at 2^20, the serial chain alone half of
+// it.  A setup issues many calls over the same generator (one per 2^20-scalar chunk and per key vector), so the
+// affine table of the default (GLV) form is kept in library-owned HBM, keyed by (device, curve, outerc, windowSize,
+// chosen table window, base bytes): four per device, least recently used out, pinned while a caller is between
+// tab_get and its last launch — the FFT plan cache's rules (fft.hip).  OZK_FB_TABLE_CACHE=0: per-call tables.
+struct FbTab {
+  int device = -1, type = 0, outerc = 0, ws = 0, wt = 0, oc = 0;
+  uint8_t base[192];
+  uint8_t* mem = nullptr;
+  u32 *aff = nullptr, *aff_phi = nullptr, *d_base = nullptr;
+  hipEvent_t ready = nullptr;
+  unsigned long long last_use = 0;
+  int refs = 0;
+};
+constexpr int FB_TABS = 4;  // per device
+static pthread_mutex_t g_tab_mu = PTHREAD_MUTEX_INITIALIZER;
+static std::vector<FbTab*> g_tabs;  // guarded by g_tab_mu
+static unsigned long long g_tab_clock = 0;
+
+static void tab_free(FbTab* t) {   // (g_tab_mu held)
+  int cur = 0;
+  const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+  if (t->mem) {
+    (void)hipSetDevice(t->device);
+    (void)hipFree(t->mem);   // waits for the kernels already enqueued
+  }
+  if (t->ready) (void)hipEventDestroy(t->ready);
+  if (have_cur) (void)hipSetDevice(cur);
+  delete t;
+}
+static void tab_release(FbTab* t) {
+  pthread_mutex_lock(&g_tab_mu);
+  t->refs--;
+  int on_dev = 0;
+  for (FbTab* q : g_tabs) on_dev += q->device == t->device;
+  if (on_dev > FB_TABS && t->refs == 0) {   // a cache that grew because every table was pinned shrinks back
+    FbTab* victim = nullptr;
+    for (FbTab* q : g_tabs)
+      if (q->device == t->device && q->refs == 0 && (!victim || q->last_use < victim->last_use)) victim = q;
+    if (victim) {
+      g_tabs.erase(std::find(g_tabs.begin(), g_tabs.end(), victim));
+      tab_free(victim);
+    }
+  }
+  pthread_mutex_unlock(&g_tab_mu);
+}
+struct TabPin {
+  FbTab* t = nullptr;
+  ~TabPin() {
+    if (t) tab_release(t);
+  }
+};
+void fb_table_cache_release() {
+  pthread_mutex_lock(&g_tab_mu);
+  for (size_t i = 0; i < g_tabs.size();) {  // pinned tables (a call in flight on another thread) stay
+    if (g_tabs[i]->refs == 0) {
+      tab_free(g_tabs[i]);
+      g_tabs.erase(g_tabs.begin() + (long)i);
+    } else {
+      i++;
+    }
+  }
+  pthread_mutex_unlock(&g_tab_mu);
+}
+
+// the cached affine table for (current device, curve, outerc, ws, fp.wt, base), PINNED, its build enqueued on `st`
+// (in the caller's workspace) if it is new; fp.aff / fp.aff_phi are set.  Only for fp.affine.
+template <class CV>
+static int tab_get(FbPlan* fp, int outerc, int ws, int n, const uint8_t* base_host, void* wsp, size_t wsb, hipStream_t st,
+                   FbTab** out) {
+  using IO = CurveIO<CV>;
+  constexpr int type = std::is_same<CV, G1Cfg>::value ? OZK_G1 : OZK_G2;
+  constexpr size_t base_bytes = type == OZK_G1 ? 96 : 192;
+  int dev = 0;
+  OZK_HIP(hipGetDevice(&dev));
+  pthread_mutex_lock(&g_tab_mu);
+  FbTab* hit = nullptr;
+  FbTab* victim = nullptr;
+  int on_dev = 0;
+  for (FbTab* t : g_tabs) {
+    if (t->device != dev) continue;
+    on_dev++;
+    if (t->type == type && t->outerc == outerc && t->ws == ws && t->wt == fp->wt && t->oc == fp->oc &&
+        memcmp(t->base, base_host, base_bytes) == 0) {
+      hit = t;
+      break;
+    }
+    if (t->refs == 0 && (!victim || t->last_use < victim->last_use)) victim = t;
+  }
+  int rc = OZK_OK;
+  if (!hit) {
+    if (on_dev >= FB_TABS && victim) {
+      g_tabs.erase(std::find(g_tabs.begin(), g_tabs.end(), victim));
+      tab_free(victim);
+    }
+    FbTab* nt = new (std::nothrow) FbTab();
+    if (!nt) {
+      pthread_mutex_unlock(&g_tab_mu);
+      return fail(OZK_E_NOMEM, "out of host memory");
+    }
+    nt->device = dev;
+    nt->type = type;
+    nt->outerc = outerc;
+    nt->ws = ws;
+    nt->wt = fp->wt;
+    nt->oc = fp->oc;
+    memcpy(nt->base, base_host, base_bytes);
+    const size_t entries = (size_t)fp->oc << fp->wt;
+    const size_t half = pad256(entries * IO::AFF_WORDS * 4);
+    hipError_t e = hipMalloc((void**)&nt->mem, 2 * half + 256);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&nt->ready, hipEventDisableTiming);
+    if (e != hipSuccess) {
+      tab_free(nt);
+      pthread_mutex_unlock(&g_tab_mu);
+      return fail(OZK_E_NOMEM, "fixed-base table allocation (%zu bytes) failed: %s", 2 * half + 256, hipGetErrorString(e));
+    }
+    nt->aff = (u32*)nt->mem;
+    nt->aff_phi = (u32*)(nt->mem + half);
+    nt->d_base = (u32*)(nt->mem + 2 * half);
+    // (from the table's own copy of the base: host memory that outlives the asynchronous copy)
+    e = hipMemcpyAsync(nt->d_base, nt->base, base_bytes, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) rc = fail(OZK_E_NO_DEVICE, "hipMemcpyAsync failed: %s", hipGetErrorString(e));
+    if (!rc) rc = fb_build<CV>(*fp, outerc, ws, n, nt->d_base, wsp, wsb, st, nt->aff, nt->aff_phi);
+    if (!rc && hipEventRecord(nt->ready, st) != hipSuccess) rc = fail(OZK_E_NO_DEVICE, "hipEventRecord failed");
+    if (rc) {
+      tab_free(nt);
+      pthread_mutex_unlock(&g_tab_mu);
+      return rc;
+    }
+    g_tabs.push_back(nt);
+    hit = nt;
+  }
+  hit->last_use = ++g_tab_clock;
+  hit->refs++;
+  hipEvent_t ev = hit->ready;
+  pthread_mutex_unlock(&g_tab_mu);
+  const hipError_t we = hipStreamWaitEvent(st, ev, 0);   // a no-op on the stream that built it
+  if (we != hipSuccess) {
+    tab_release(hit);
+    return fail(OZK_E_NO_DEVICE, "hipStreamWaitEvent failed: %s", hipGetErrorString(we));
+  }
+  fp->aff = hit->aff;
+  fp->aff_phi = hit->aff_phi;
+  *out = hit;
+  return OZK_OK;
+}
+
+// table for a call whose base is known to the HOST (the `*_host` entry points, ozk_fixed_batch_msm_base_dev): the
+// cached one when the form allows, else built in the workspace from a copy of the base at `d_base_scratch`
+template <class CV>
+static int fb_table_host_base(int outerc, int ws, int n, const uint8_t* base_host, u32* d_base_scratch, void* wsp, size_t wsb,
+                              hipStream_t st, FbPlan* fp, TabPin* pin) {
+  constexpr size_t base_bytes = std::is_same<CV, G1Cfg>::value ? 96 : 192;
+  *fp = fb_choose(outerc, ws, n);
+  if (fp->affine && env_int("OZK_FB_TABLE_CACHE", 1)) return tab_get<CV>(fp, outerc, ws, n, base_host, wsp, wsb, st, &pin->t);
+  OZK_HIP(hipMemcpyAsync(d_base_scratch, base_host, base_bytes, hipMemcpyHostToDevice, st));
+  OZK_HIP(hipStreamSynchronize(st));   // `base_host` is the caller's (pageable) memory
+  return fb_build<CV>(*fp, outerc, ws, n, d_base_scratch, wsp, wsb, st);
 }
 
 }  // namespace ozk
@@ -503,13 +686,37 @@ int ozk_fixed_batch_msm_compact_dev(int32_t outerc, int32_t ws, int32_t n, const
                                 (hipStream_t)stream, 1);
 }
 
+// the same with the base point given as HOST bytes (wire format, 96 / 192 B; scalars and results stay in device
+// memory), so that the window table can come from the cache: what a caller that issues many batches over one
+// generator should use.  compact != 0: 32-byte coordinates (ozk_fixed_batch_msm_compact_dev's layout).
+int ozk_fixed_batch_msm_base_dev(int32_t outerc, int32_t ws, int32_t n, const uint8_t* base_host, const void* d_scalars,
+                                 int32_t bn_type, void* d_out, int32_t compact, void* d_workspace, size_t workspace_bytes,
+                                 void* stream) {
+  if (!base_host || !d_scalars || !d_out || !d_workspace) return fail(OZK_E_INVALID, "null pointer argument");
+  int rc = fb_check_args(outerc, ws, n);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  FbPlan fp;
+  TabPin pin;  // held until the launches below are enqueued
+  if (bn_type == OZK_G1) {
+    const FbLayout L = fb_layout<G1Cfg>(outerc, ws, n, d_workspace, workspace_bytes);
+    if (L.bytes > workspace_bytes) return fail(OZK_E_INVALID, "workspace too small: need %zu bytes, got %zu", L.bytes, workspace_bytes);
+    if ((rc = fb_table_host_base<G1Cfg>(outerc, ws, n, base_host, L.base, d_workspace, workspace_bytes, st, &fp, &pin))) return rc;
+    return fb_apply<G1Cfg>(fp, outerc, ws, n, 0, n, d_scalars, d_out, compact ? 24 : 48, d_workspace, workspace_bytes, st, compact ? 1 : 0);
+  }
+  const FbLayout L = fb_layout<G2Cfg>(outerc, ws, n, d_workspace, workspace_bytes);
+  if (L.bytes > workspace_bytes) return fail(OZK_E_INVALID, "workspace too small: need %zu bytes, got %zu", L.bytes, workspace_bytes);
+  if ((rc = fb_table_host_base<G2Cfg>(outerc, ws, n, base_host, L.base, d_workspace, workspace_bytes, st, &fp, &pin))) return rc;
+  return fb_apply<G2Cfg>(fp, outerc, ws, n, 0, n, d_scalars, d_out, compact ? 48 : 96, d_workspace, workspace_bytes, st, compact ? 1 : 0);
+}
+
 static int fixed_batch_host(int32_t outerc, int32_t ws, int32_t n, const uint8_t* base, const uint8_t* scalars,
                             int32_t bn_type, int32_t task_id, uint8_t* out, int compact) {
   if (!base || !scalars || !out) return fail(OZK_E_INVALID, "null pointer argument");
   int rc = fb_check_args(outerc, ws, n);
   if (rc) return rc;
   const bool g1 = bn_type == OZK_G1;
-  const size_t base_bytes = g1 ? 96 : 192, sc_bytes = (size_t)n * 32;
+  const size_t sc_bytes = (size_t)n * 32;
   const size_t out_bytes = (size_t)n * (g1 ? 192 : 384) / (compact ? 2 : 1);
   const size_t wsb = ozk_fixed_batch_msm_workspace_bytes(outerc, ws, n, bn_type);
   CtxGuard g;
@@ -519,15 +726,15 @@ static int fixed_batch_host(int32_t outerc, int32_t ws, int32_t n, const uint8_t
   if ((rc = ctx_reserve(c, a2 + wsb + 256))) return rc;
   uint8_t* d = c->arena;
   hipStream_t st = c->st[0], cp = c->st[2];
-  OZK_HIP(hipMemcpyAsync(d, base, base_bytes, hipMemcpyHostToDevice, st));
-  OZK_HIP(hipStreamSynchronize(st));   // `base` is the caller's (pageable) memory
   // The table (~1 ms at window 17, mostly the serial doubling chain) is built while the scalars are on their way;
   // the per-scalar part then runs in ranges, each range's results going back to the host (on the copy stream,
   // staged through the pinned ring) while the next ranges are computed: the output is 6 (compact: 3) times the
   // input, so the call is bound by the download and nothing else should add to it.
   const int osw = (g1 ? 48 : 96) / (compact ? 2 : 1);
   FbPlan fp;
-  rc = g1 ? fb_table<G1Cfg>(outerc, ws, n, d, d + a2, wsb, st, &fp) : fb_table<G2Cfg>(outerc, ws, n, d, d + a2, wsb, st, &fp);
+  TabPin pin;  // the cached table stays pinned until every range below is enqueued
+  rc = g1 ? fb_table_host_base<G1Cfg>(outerc, ws, n, base, (u32*)d, d + a2, wsb, st, &fp, &pin)
+          : fb_table_host_base<G2Cfg>(outerc, ws, n, base, (u32*)d, d + a2, wsb, st, &fp, &pin);
   if (rc) return rc;
   if ((rc = staged_h2d(c, d + a0, scalars, sc_bytes, cp))) return rc;
   OZK_HIP(hipEventRecord(c->ev[0], cp));
@@ -596,13 +803,15 @@ int ozk_fixed_double_batch_msm_host(int32_t outerc1, int32_t ws1, int32_t outerc
   if ((rc = ctx_reserve(c, a2 + wsb + 256))) return rc;
   uint8_t* d = c->arena;
   hipStream_t st = c->st[0];
-  OZK_HIP(hipMemcpyAsync(d, base_g1, 96, hipMemcpyHostToDevice, st));
-  OZK_HIP(hipMemcpyAsync(d + 256, base_g2, 192, hipMemcpyHostToDevice, st));
-  OZK_HIP(hipStreamSynchronize(st));
+  // (tables from the cache when the form allows; the G1 and G2 parts share the workspace, so a G2 table that has to
+  // be built is built after the G1 part's kernels, in stream order)
   if ((rc = staged_h2d(c, d + a0, scalars, sc_bytes, st))) return rc;
-  rc = fixed_batch_dev<G1Cfg>(outerc1, ws1, n, d, d + a0, d + a1, 144, d + a2, wsb, st);
-  if (rc) return rc;
-  rc = fixed_batch_dev<G2Cfg>(outerc2, ws2, n, d + 256, d + a0, d + a1 + 192, 144, d + a2, wsb, st);
+  FbPlan fp1, fp2;
+  TabPin pin1, pin2;
+  if ((rc = fb_table_host_base<G1Cfg>(outerc1, ws1, n, base_g1, (u32*)d, d + a2, wsb, st, &fp1, &pin1))) return rc;
+  if ((rc = fb_apply<G1Cfg>(fp1, outerc1, ws1, n, 0, n, d + a0, d + a1, 144, d + a2, wsb, st, 0))) return rc;
+  if ((rc = fb_table_host_base<G2Cfg>(outerc2, ws2, n, base_g2, (u32*)(d + 256), d + a2, wsb, st, &fp2, &pin2))) return rc;
+  rc = fb_apply<G2Cfg>(fp2, outerc2, ws2, n, 0, n, d + a0, d + a1 + 192, 144, d + a2, wsb, st, 0);
   if (rc) return rc;
   return staged_d2h(c, out, d + a1, out_bytes, st);
 }

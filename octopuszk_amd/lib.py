@@ -61,6 +61,7 @@ _SIGS = {
     "ozk_field_batch_mul_dev": (ctypes.c_int, [vp, i32, vp, vp]),
     "ozk_fixed_batch_msm_compact_dev": (ctypes.c_int, [i32, i32, i32, vp, vp, i32, vp, vp, sz, vp]),
     "ozk_fixed_batch_msm_compact_host": (ctypes.c_int, [i32, i32, i32, vp, vp, i32, i32, vp]),
+    "ozk_fixed_batch_msm_base_dev": (ctypes.c_int, [i32, i32, i32, vp, vp, i32, vp, i32, vp, sz, vp]),
     "ozk_fft_compact_host": (ctypes.c_int, [vp, i32, vp, i32, vp]),
     "ozk_fft_compact_dev": (ctypes.c_int, [vp, i32, vp, vp, vp, sz, vp]),
     "ozk_tuning_reload": (ctypes.c_int, []),

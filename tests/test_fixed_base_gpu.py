@@ -148,3 +148,80 @@ def test_fixed_base_host_ranges_equal_one_range(bn, compact, monkeypatch):
         else:
             got = [int.from_bytes(rec[j * cw:(j + 1) * cw], "little" if compact else "big") for j in range(4)]
             assert ((got[0], got[1]), (got[2], got[3])) == (want[0], want[1]), i
+
+
+def test_fixed_base_table_cache_same_bytes_as_per_call_tables(monkeypatch):
+    """The window table of a base is cached per device (msm_fixed.hip, FbTab): every call — first (miss), repeated
+    (hit), after six other bases have pushed it out of the four slots (rebuild), G1 and G2, both output layouts, host
+    and device-resident entry — returns the bytes of the per-call-table path (OZK_FB_TABLE_CACHE=0), and sampled
+    elements equal the oracle's."""
+    import ctypes
+    import numpy as np
+    import torch
+    from octopuszk_amd import lib
+    L = lib.load()
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    n, w, outerc = 3000, 13, 20
+    rng = np.random.default_rng(77)
+    sc = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    sc[:, 31] &= 0x1F
+    d_sc = torch.from_numpy(sc.reshape(-1)).cuda()
+    st = int(torch.cuda.current_stream().cuda_stream)
+
+    def bases(bn):
+        G = o.G1 if bn == 1 else o.G2
+        return [G.mul(G.one, 0xABCDEF + 17 * k) for k in range(7)]
+
+    def host_call(bn, bw, compact):
+        out = np.zeros(n * (192 if bn == 1 else 384) // (2 if compact else 1), dtype=np.uint8)
+        if compact:
+            lib.check(L.ozk_fixed_batch_msm_compact_host(outerc, w, n, vp(bw), vp(sc), bn, 0, vp(out)))
+        else:
+            lib.check(L.ozk_fixed_batch_msm_host(outerc, w, outerc, 1 << w, n, 254, vp(bw), vp(sc), bn, 0, vp(out)))
+        return out.tobytes()
+
+    def dev_call(bn, bw, compact):
+        wsb = int(L.ozk_fixed_batch_msm_workspace_bytes(outerc, w, n, bn))
+        ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+        out = torch.zeros(n * (192 if bn == 1 else 384) // (2 if compact else 1), dtype=torch.uint8, device="cuda")
+        lib.check(L.ozk_fixed_batch_msm_base_dev(outerc, w, n, vp(bw), int(d_sc.data_ptr()), bn, int(out.data_ptr()), compact,
+                                                 int(ws.data_ptr()), wsb, st))
+        torch.cuda.synchronize()
+        return bytes(out.cpu().numpy())
+
+    for bn in (1, 2):
+        G = o.G1 if bn == 1 else o.G2
+        pts = bases(bn)
+        wires = [np.frombuffer(o.g1_to_wire(P) if bn == 1 else o.g2_to_wire(P), dtype=np.uint8).copy() for P in pts]
+        # reference bytes: per-call tables
+        monkeypatch.setenv("OZK_FB_TABLE_CACHE", "0")
+        lib.check(L.ozk_tuning_reload())
+        ref = {(k, c): host_call(bn, wires[k], c) for k in range(7) for c in (0, 1)}
+        monkeypatch.delenv("OZK_FB_TABLE_CACHE")
+        lib.check(L.ozk_tuning_reload())
+        # miss, hit, the other layout (hit), the device-resident entry (hit)
+        assert host_call(bn, wires[0], 0) == ref[(0, 0)]
+        assert host_call(bn, wires[0], 0) == ref[(0, 0)]
+        assert host_call(bn, wires[0], 1) == ref[(0, 1)]
+        assert dev_call(bn, wires[0], 0) == ref[(0, 0)]
+        assert dev_call(bn, wires[0], 1) == ref[(0, 1)]
+        # six more bases: base 0 leaves the four slots; then it is rebuilt
+        for k in range(1, 7):
+            assert dev_call(bn, wires[k], 1) == ref[(k, 1)], k
+            assert host_call(bn, wires[k], 0) == ref[(k, 0)], k
+        assert host_call(bn, wires[0], 1) == ref[(0, 1)]
+        # against the oracle (compact layout: X | Y | Z little-endian)
+        cw = 32
+        per = 3 * cw * (1 if bn == 1 else 2)
+        raw = ref[(3, 1)]
+        for i in (0, 1, n // 2, n - 1):
+            s_i = int.from_bytes(sc[i].tobytes(), "little")
+            want = G.to_affine(G.mul(pts[3], s_i))
+            rec = raw[i * per:(i + 1) * per]
+            if bn == 1:
+                got = tuple(int.from_bytes(rec[j * cw:(j + 1) * cw], "little") for j in range(3))
+                assert (got[0], got[1]) == (want[0], want[1]) and got[2] == 1, i
+            else:
+                v = [int.from_bytes(rec[j * cw:(j + 1) * cw], "little") for j in range(6)]
+                assert ((v[0], v[1]), (v[2], v[3])) == (tuple(want[0]), tuple(want[1])), i
+    lib.check(L.ozk_host_cache_release())

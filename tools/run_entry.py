@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run ONE entry point a few times with inputs resident in HBM (for `rocprofv3 --kernel-trace --stats -- python3
-tools/run_entry.py <what> [reps]`).  what: fft22 | fixed_g1 | fixed_g2 | var_g2 | qap21 | var_g1 | prove"""
+tools/run_entry.py <what> [reps]`).  what: fft22 | fixed_g1 | fixed_g2 | fixed_g1_rebuild | fixed_g2_rebuild (window table rebuilt per call, the form of rounds 1-3) | var_g2 | qap21 | var_g1 | prove"""
 import ctypes
 import os
 import sys
@@ -51,14 +51,19 @@ def main():
         ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
         om = le32(pow(FR_ROOT, FR // n, FR))
         fn = lambda: ozk.check(L.ozk_fft_dev(ptr(d_in), n, ctypes.cast(om, ctypes.c_void_p), ptr(d_out), ptr(ws), wsb, st))
-    elif what in ("fixed_g1", "fixed_g2"):
-        n, bn = 1 << 20, 1 if what == "fixed_g1" else 2
+    elif what in ("fixed_g1", "fixed_g2", "fixed_g1_rebuild", "fixed_g2_rebuild"):
+        n, bn = 1 << 20, 1 if "g1" in what else 2
         sc = scalars(n, 4)
-        base = torch.from_numpy(np.frombuffer(G1_ONE if bn == 1 else G2_ONE, dtype=np.uint8).copy()).cuda()
+        base_host = np.frombuffer(G1_ONE if bn == 1 else G2_ONE, dtype=np.uint8).copy()
+        base = torch.from_numpy(base_host).cuda()
         d_out = torch.empty(n * (192 if bn == 1 else 384), dtype=torch.uint8, device="cuda")
         wsb = int(L.ozk_fixed_batch_msm_workspace_bytes(15, 17, n, bn))
         ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
-        fn = lambda: ozk.check(L.ozk_fixed_batch_msm_dev(15, 17, n, ptr(base), ptr(sc), bn, ptr(d_out), ptr(ws), wsb, st))
+        if what.endswith("_rebuild"):   # base in device memory: the table is built inside every call
+            fn = lambda: ozk.check(L.ozk_fixed_batch_msm_dev(15, 17, n, ptr(base), ptr(sc), bn, ptr(d_out), ptr(ws), wsb, st))
+        else:                           # base as host bytes: the table comes from the per-device cache after the first call
+            fn = lambda: ozk.check(L.ozk_fixed_batch_msm_base_dev(15, 17, n, base_host.ctypes.data_as(ctypes.c_void_p), ptr(sc), bn,
+                                                                  ptr(d_out), 0, ptr(ws), wsb, st))
     elif what == "var_g2":
         n = 1 << 20
         base = torch.from_numpy(np.frombuffer(G2_ONE, dtype=np.uint8).copy()).cuda()
