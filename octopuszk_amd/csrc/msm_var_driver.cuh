@@ -469,12 +469,19 @@ template <class CV>
 int var_msm_tail(int n, void* tail, size_t tail_bytes, void* d_out, hipStream_t st,
                         hipEvent_t order_ev = nullptr, int mode = TAIL_LATENCY) {
   using CT = CV;
-  const MsmPlan p = make_plan(n);
+  MsmPlan p = make_plan(n);
   MsmLayout L;
   L.m1 = (((size_t)1 << p.cb) + p.S - 1) / p.S;
   const size_t tneed = tail_layout<CV>(p, L, tail, tail_bytes);
   if (tneed > tail_bytes) return fail(OZK_E_INVALID, "tail buffer too small: need %zu bytes, got %zu", tneed, tail_bytes);
   const TailShape shape = tail_shape(mode);
+  if (shape.fused && mode == TAIL_LATENCY) {
+    // the fused first level of a LONE tail: 8 buckets per lane for G1 (2^20: single MSM 2.63-2.71 -> 2.51-2.53 ms on
+    // one box; 16: 2.60), the plan's 4 for G2 (8: 7.43 against 7.38 ms).  The buffers are sized for the plan's S,
+    // which is never larger, so the fewer elements of a wider first level always fit.
+    const int s_lat = env_int("OZK_MSM_S_LAT", std::is_same<CV, G1Cfg>::value ? 8 : p.S);
+    if (s_lat >= p.S && s_lat <= 64) p.S = 1 << ilog2((uint32_t)s_lat);
+  }
   launch_wsum0<CV>(p, L, st, env_int("OZK_MSM_WSUM0_PRIO", 0), shape.fused);
   int m_in, g, k = 0;
   first_level_shape(p, shape.fused, &m_in, &g);

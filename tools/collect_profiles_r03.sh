@@ -25,37 +25,43 @@ python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/b2.out 2> 
 python bench.py --steps 100 --warmup 5 --no-cpu-baseline > $O/b3.out 2> $O/b3.err && line $O/b3.out $O/r03_bench_100_steps.json
 python bench.py --steps 100 --warmup 5 --no-cpu-baseline --schedule pipeline > $O/b4.out 2> $O/b4.err && line $O/b4.out $O/r03_bench_two_stage.json
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --in-flight 1 --schedule pipeline > $O/b5.out 2> $O/b5.err && line $O/b5.out $O/r03_bench_in_flight_1.json
-echo "bench done"
+echo "bench done $SECONDS s"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $O/kt_default --output-format csv -- python3 $R/bench.py --no-cpu-baseline --timed-only --steps 100 > $O/kt_default.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/kt_single --output-format csv -- python3 $R/bench.py --no-cpu-baseline --timed-only --steps 10 --in-flight 1 --schedule pipeline > $O/kt_single.log 2>&1
 cp $O/kt_default/*/*kernel_stats.csv $O/r03_kernel_stats_default.csv
 cp $O/kt_single/*/*kernel_stats.csv $O/r03_kernel_stats_single.csv
-echo "bench traces done"
-for w in fft22 fixed_g1 fixed_g2 var_g2 qap21; do
+echo "bench traces done $SECONDS s"
+for w in fft22 fixed_g1 fixed_g2 fixed_g1_rebuild fixed_g2_rebuild var_g2 qap21; do
   rocprofv3 --kernel-trace --stats -d $O/kt_$w --output-format csv -- python3 $R/tools/run_entry.py $w 10 > $O/kt_$w.log 2>&1
   cp $O/kt_$w/*/*kernel_stats.csv $O/r03_kernel_stats_$w.csv
-  echo "$w done"
+  echo "$w done $SECONDS s"
 done
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch --output-format csv -- python3 $R/bench.py --no-cpu-baseline --timed-only --steps 4 --warmup 1 > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write --output-format csv -- python3 $R/bench.py --no-cpu-baseline --timed-only --steps 4 --warmup 1 > $O/pmc_write.log 2>&1
-echo "hbm pmc done"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch_fft --output-format csv -- python3 $R/tools/run_entry.py fft22 3 > $O/pmc_fetch_fft.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write_fft --output-format csv -- python3 $R/tools/run_entry.py fft22 3 > $O/pmc_write_fft.log 2>&1
+echo "hbm pmc done $SECONDS s"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU --kernel-trace -d $O/pmc_sq1 --output-format csv -- python3 $R/bench.py --no-cpu-baseline --timed-only --steps 4 --warmup 1 > $O/pmc_sq1.log 2>&1
 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -d $O/pmc_sq2 --output-format csv -- python3 $R/bench.py --no-cpu-baseline --timed-only --steps 4 --warmup 1 > $O/pmc_sq2.log 2>&1
-echo "sq pmc done"
+echo "sq pmc done $SECONDS s"
 cd $R
 { hdr "lone MSM 2^20 (bench --in-flight 1 --schedule pipeline), last step"; python tools/prof_summary.py $O/kt_single; } > $O/r03_timeline_single_msm.txt
 { hdr "three-stage schedule, steady state (bench --timed-only --steps 100 under rocprofv3 --kernel-trace)"; python tools/timeline_steady.py $O/kt_default 2 3; } > $O/r03_timeline_three_stage.txt
 python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write > $O/r03_pmc_hbm_summary.csv
 python tools/pmc_summary.py $O/pmc_sq1 $O/pmc_sq2 > $O/r03_pmc_sq_summary.csv
+python tools/pmc_summary.py $O/pmc_fetch_fft $O/pmc_write_fft > $O/r03_pmc_hbm_fft_summary.csv
 { hdr "serial Groth16 at 2^20 constraints (tools/groth16_prove.py 20 8)"; python tools/groth16_prove.py 20 8 2>&1 | grep -v amdgpu.ids; } > $O/r03_groth16_prove_2p20.txt
 grep '^{' $O/r03_groth16_prove_2p20.txt | python -c "
 import json,sys
 j=json.loads(sys.stdin.read()); j['evidence_commit']='$COMMIT'; print(json.dumps(j))" > $O/r03_groth16_prove_2p20.json
 { hdr "JNI-shaped entry points from fresh pageable buffers (tools/host_path.py)"; python tools/host_path.py 2>&1 | grep -v amdgpu.ids; } > $O/r03_host_path.txt
+{ hdr "the same script with the harness's uploads from PAGEABLE memory (tools/host_path.py --pageable-uploads): the stale registrations of the runtime evict the process's queues when the ranges are recycled, DESIGN.md section 6"; python tools/host_path.py --pageable-uploads 2>&1 | grep "double\|var_msm_host G1"; } > $O/r03_host_path_pageable_uploads.txt
+{ hdr "first operation after T ms of idle device (tools/idle_wake_probe.py)"; python tools/idle_wake_probe.py 2>&1 | grep -v amdgpu.ids | cut -c1-90; } > $O/r03_idle_wake_probe.txt
+{ hdr "fill and drain of the three-stage schedule: total = c0 + K * s over bursts of 10-200 MSMs (tools/sched_probe.py --fit)"; python tools/sched_probe.py --sched p3 --depth 4 --fit 2>&1 | grep -v amdgpu.ids | cut -c1-60; } > $O/r03_fill_drain_fit.txt
 { hdr "call-time distributions, interleaved with other GPU work and allocations (tools/host_jitter.py 200 --interleaved --no-gc)"; python tools/host_jitter.py 200 --interleaved --no-gc 2>&1 | grep -v amdgpu.ids; } > $O/r03_host_jitter.txt
 { hdr "device-resident MSM time by size (tools/size_sweep.py)"; python tools/size_sweep.py 2>&1 | grep -v amdgpu.ids; } > $O/r03_size_sweep.txt
 { hdr "schedules (tools/sched_probe.py, 200 MSMs each)"; for a in "--sched p3 --depth 4" "--sched p3 --depth 4 --prof 2" "--sched p3 --depth 4 --prof 1" "--sched p3 --depth 4 --prof 26" "--sched p2" "--sched p2 --prof 2" "--sched p3 --depth 4 --prepared"; do python tools/sched_probe.py --reps 200 $a 2>&1 | grep -v amdgpu.ids; done; } > $O/r03_schedules.txt
 { echo "commit $COMMIT"; date -u; python -c "import torch; print(torch.cuda.get_device_name(0))"; ls $O | grep r03_; } > $O/r03_MANIFEST.txt
-rm -rf $O/kt_* $O/pmc_fetch $O/pmc_write $O/pmc_sq1 $O/pmc_sq2 $O/*.out
-du -sh $O; ls $O
+rm -rf $O/kt_* $O/pmc_fetch $O/pmc_write $O/pmc_fetch_fft $O/pmc_write_fft $O/pmc_sq1 $O/pmc_sq2 $O/*.out
+echo "all done $SECONDS s"; du -sh $O; ls $O
