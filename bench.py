@@ -290,13 +290,20 @@ def main():
     lat = []
     alone = None
     if not args.timed_only:
+        # (through the single-call entry point ozk_var_msm_dev, the way one caller with one MSM uses the library: its
+        # tail takes the latency shape; a lone MSM pushed through the pipeline object would get the throughput-shaped
+        # tail, 0.2-0.3 ms slower when nothing runs beside it)
+        lone = dev.VarMsmWorkspace(n, 1)
+        lone.run(msm_bases, scalars, prepared=args.prepared)
         ozk.check(L.ozk_prof_enable(2))
         for _ in range(5):
             torch.cuda.synchronize()
             l0 = time.perf_counter()
-            run_steps(1)
+            lone_out = lone.run(msm_bases, scalars, prepared=args.prepared)
             torch.cuda.synchronize()
             lat.append(time.perf_counter() - l0)
+        if world == 1 and bytes(lone_out.cpu().numpy()) != result_bytes:
+            raise SystemExit("bench: the single-call entry point returned a different point")
         a4, al = (ctypes.c_double * 4)(), ctypes.c_int()
         ozk.check(L.ozk_prof_dominant_kernel_stats(a4, ctypes.byref(al)))
         ozk.check(L.ozk_prof_enable(0))
