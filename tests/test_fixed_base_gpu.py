@@ -225,3 +225,54 @@ def test_fixed_base_table_cache_same_bytes_as_per_call_tables(monkeypatch):
                 v = [int.from_bytes(rec[j * cw:(j + 1) * cw], "little") for j in range(6)]
                 assert ((v[0], v[1]), (v[2], v[3])) == (tuple(want[0]), tuple(want[1])), i
     lib.check(L.ozk_host_cache_release())
+
+
+def test_fixed_base_table_cache_under_concurrent_callers():
+    """Four host threads issue fixed-base batches over SIX bases through the cached-table entry points at once (more
+    bases than the four slots per device: tables are evicted while other threads hold theirs pinned); every result
+    must be the bytes the same call returns alone with per-call tables."""
+    import ctypes
+    import threading
+    import numpy as np
+    from octopuszk_amd import lib
+    L = lib.load()
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    n, w, outerc = 2500, 12, 22
+    rng = np.random.default_rng(5)
+    sc = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    sc[:, 31] &= 0x1F
+    cases = []
+    for bn in (1, 2):
+        G = o.G1 if bn == 1 else o.G2
+        for k in range(3):
+            P = G.mul(G.one, 0x5151 + 29 * k + bn)
+            cases.append((bn, np.frombuffer(o.g1_to_wire(P) if bn == 1 else o.g2_to_wire(P), dtype=np.uint8).copy()))
+
+    def call(bn, bw):
+        out = np.zeros(n * (96 if bn == 1 else 192), dtype=np.uint8)
+        lib.check(L.ozk_fixed_batch_msm_compact_host(outerc, w, n, vp(bw), vp(sc), bn, 0, vp(out)))
+        return out.tobytes()
+
+    os_env = __import__("os").environ
+    os_env["OZK_FB_TABLE_CACHE"] = "0"
+    lib.check(L.ozk_tuning_reload())
+    try:
+        ref = [call(bn, bw) for bn, bw in cases]
+    finally:
+        del os_env["OZK_FB_TABLE_CACHE"]
+        lib.check(L.ozk_tuning_reload())
+    bad = []
+
+    def worker(t):
+        for r in range(6):
+            i = (t * 5 + r * 7) % len(cases)
+            if call(*cases[i]) != ref[i]:
+                bad.append((t, r, i))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not bad, bad
+    lib.check(L.ozk_host_cache_release())
