@@ -14,7 +14,7 @@ parts the Java does on the CPU in the SETUP (R1CS construction, Lagrange coeffic
 of A_i(t), B_i(t), C_i(t)), and device buffers for everything else:
 
   * setup: the five fixed-base batches write the proving key straight into the wire-in format of the
-    variable-base MSM (ozk_fixed_batch_msm_base_dev, compact layout), so the key never leaves HBM;
+    variable-base MSM (ozk_fixed_batch_msm_compact_dev), so the key never leaves HBM;
   * prove: the assignment goes up once (32-byte elements), the constraint matrices sit in HBM as CSR and are
     evaluated there (ozk_r1cs_evaluate_dev), ozk_qap_witness_dev leaves coefficientsH in HBM, the
     MSMs run over bases prepared once per key (ozk_var_msm_prepare_dev) — G1 through a two-stage pipeline on
@@ -447,15 +447,15 @@ def batch_msm_dev(scalar_size: int, window_size: int, base_wire: bytes, scalars,
     outerc = (scalar_size + window_size - 1) // window_size   # FixedBaseMSM.java:212
     if outerc * window_size < 254:
         raise _lib.OzkError("window plan covers %d bits of a 254-bit scalar" % (outerc * window_size))
+    d_base = _dev_bytes(base_wire)
     d_sc = scalars if on_device else _dev_bytes(_le32(scalars))
     out = torch.empty(n * (96 if type_ == 1 else 192), dtype=torch.uint8, device="cuda")
     wsb = int(L.ozk_fixed_batch_msm_workspace_bytes(outerc, window_size, n, type_))
     ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
-    # the base as host bytes: the setup issues every batch over one of two generators, so all but the first of each
-    # take their window table from the library's cache (msm_fixed.hip)
-    base_buf = ctypes.create_string_buffer(bytes(base_wire), len(base_wire))
-    _lib.check(L.ozk_fixed_batch_msm_base_dev(outerc, window_size, n, ctypes.cast(base_buf, ctypes.c_void_p), _ptr(d_sc),
-                                              type_, _ptr(out), 1, _ptr(ws), wsb, _stream()))
+    # (per-call window table: the five batches of ONE setup differ in size, hence in the table window the library
+    # chooses, so the table cache of ozk_fixed_batch_msm_base_dev would only add its allocations here — 22 -> 85 ms)
+    _lib.check(L.ozk_fixed_batch_msm_compact_dev(outerc, window_size, n, _ptr(d_base), _ptr(d_sc), type_, _ptr(out),
+                                                 _ptr(ws), wsb, _stream()))
     torch.cuda.current_stream().synchronize()   # ws / d_sc die here
     return out
 
