@@ -507,6 +507,21 @@ static int fft_core(const u32* d_in, int n, const u32* tw, u32* d_out, int out_s
       }
     if (planned) npass = planned;
   }
+  if (const char* ks = getenv("OZK_FFT_KS")) {   // experiment: explicit stage counts, e.g. "8,6,8" (must sum to log2 n)
+    int k[16], c = 0, sum = 0;
+    for (const char* q = ks; *q && c < 16;) {
+      k[c] = atoi(q);
+      sum += k[c++];
+      while (*q && *q != ',') q++;
+      if (*q == ',') q++;
+    }
+    bool ok = sum == logn && c >= 1;
+    for (int i = 0; i < c; i++) ok = ok && k[i] >= 3 && k[i] <= 10;
+    if (ok) {
+      for (int i = 0; i < c; i++) plan[i] = k[i];
+      planned = npass = c;
+    }
+  }
   int sbits = 0, cur = 0;
   u32* bufs[2] = {buf0, buf1};
   const u32* src = d_in;
