@@ -247,7 +247,7 @@ int ozk_fixed_batch_msm_compact_host(int32_t outerc, int32_t window_size, int32_
  * table — what the reference's Java side computes once per key element (getWindowTable, FixedBaseMSM.java:71-99) and
  * its native side rebuilds inside every call (algebra_msm_FixedBaseMSM.cu:851-992) — comes from a per-device cache
  * keyed by the base, so the second and later batches over one generator skip the doubling chain and the table
- * (0.65 / 2.1 ms of a 1.75 / 5.45 ms G1 / G2 call at 2^20).  The `*_host` entry points use the same cache.
+ * (0.65 / 2.1 ms of a 2.0 / 5.5 ms G1 / G2 call at 2^20).  The `*_host` entry points use the same cache.
  * compact != 0: the 32-byte little-endian layout of ozk_fixed_batch_msm_compact_dev.  Workspace:
  * ozk_fixed_batch_msm_workspace_bytes.  ozk_host_cache_release() frees the cached tables. */
 int ozk_fixed_batch_msm_base_dev(int32_t outerc, int32_t window_size, int32_t n, const uint8_t* base_host,

@@ -489,7 +489,7 @@ static int fixed_batch_dev(int outerc, int ws, int n, const void* d_base, const 
 // The window table depends only on (base, windowSize, outerc) and the size class of the call; the reference's Java
 // side computes it once per key element (getWindowTable, FixedBaseMSM.java:71-99) and its native side rebuilds it
 // inside every call (FixedBaseMSM.cu:851-992) — as this library did through round 3: doubling chain + levels +
-// batched normalisation = 0.65 ms (G1) / 2.1 ms (G2) of a 1.75 / 5.45 ms call at 2^20, the serial chain alone half of
+// batched normalisation = 0.65 ms (G1) / 2.1 ms (G2) of a 2.0 / 5.5 ms call at 2^20, the serial chain alone half of
 // it.  A setup issues many calls over the same generator (one per 2^20-scalar chunk and per key vector), so the
 // affine table of the default (GLV) form is kept in library-owned HBM, keyed by (device, curve, outerc, windowSize,
 // chosen table window, base bytes): four per device, least recently used out, pinned while a caller is between
