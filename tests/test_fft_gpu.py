@@ -98,18 +98,24 @@ def test_fft_large_properties():
     assert val(fa[0]) == s % o.R
 
 
-@pytest.mark.parametrize("tile", [512, 2048])
-def test_fft_other_tile_geometries(tile, monkeypatch):
-    """OZK_FFT_TILE selects the workgroup tile (default 1024; 2048 = two passes at 2^22, measured slower —
-    DESIGN.md): every geometry must give the same bytes."""
+@pytest.mark.parametrize("knobs", [{}, {"OZK_FFT_PLAN": "0"}, {"OZK_FFT_MAXK": "6"}, {"OZK_FFT_MAXK": "10"},
+                                   {"OZK_FFT_KS": "6,8,6"}, {"OZK_FFT_KS": "5,5,5,5"}, {"OZK_FFT_KS": "9,4,7"}],
+                         ids=lambda k: "_".join("%s%s" % (a[8:], b) for a, b in k.items()) or "default")
+def test_fft_every_pass_plan_gives_the_oracle_bytes(knobs, monkeypatch):
+    """The stages are spread over passes by a plan (default: every pass after the first even — 2^20 = 8 + 6 + 6; the
+    even split of rounds 1-2 with OZK_FFT_PLAN=0 runs the odd-stage kernels of the later passes; OZK_FFT_MAXK caps a
+    pass; OZK_FFT_KS gives the split by hand — used for 2^20 only, ignored where it does not sum to log2 n).  Every
+    plan, every kernel specialisation (first / later pass, odd / even, workspace / result output) must give the C
+    oracle's bytes; the sizes cover the default plans [6,4] [8,4] [8,6] [7,8] [7,6,4] [8,6,4] [7,6,6] [8,6,6]."""
     import ctypes
     import numpy as np
     from octopuszk_amd import lib
     L = lib.load()
-    monkeypatch.setenv("OZK_FFT_TILE", str(tile))
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
     L.ozk_tuning_reload()
     try:
-        for logn in (11, 12, 17, 20):
+        for logn in (10, 12, 14, 15, 17, 18, 19, 20):
             n = 1 << logn
             a = np.random.default_rng(logn).integers(0, 256, size=(n, 32), dtype=np.uint8)
             a[:, 31] &= 0x1F
@@ -117,9 +123,10 @@ def test_fft_other_tile_geometries(tile, monkeypatch):
             out = ctypes.create_string_buffer(64 * n)
             lib.check(L.ozk_fft_host(a.ctypes.data_as(ctypes.c_void_p), n, ctypes.cast(ctypes.c_char_p(w), ctypes.c_void_p), 0,
                                      ctypes.cast(out, ctypes.c_void_p)))
-            assert out.raw == coracle.fft_fr(a.tobytes(), n, w), (tile, logn)
+            assert out.raw == coracle.fft_fr(a.tobytes(), n, w), (knobs, logn)
     finally:
-        monkeypatch.delenv("OZK_FFT_TILE")
+        for k in knobs:
+            monkeypatch.delenv(k)
         L.ozk_tuning_reload()
 
 
