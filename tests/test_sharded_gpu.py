@@ -55,58 +55,9 @@ def _worker(rank, world, port, n, type_, bases_wire, scalars_wire, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,world", [(4096, 2), (5001, 3)])
-def test_sharded_g1_msm_equals_oracle_on_the_whole_input(n, world):
-    rng = np.random.default_rng(n)
-    G = o.G1
-    pts = [G.to_affine(G.mul(G.one, int(k))) for k in rng.integers(1, 1 << 62, size=64)]
-    bw = b"".join(o.g1_to_wire(pts[i % 64]) for i in range(n))
-    sc = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
-    sc[:, 31] &= 0x1F
-    sw = sc.tobytes()
-    want = coracle.pippenger_g1(bw, sw, n)
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, 1, bw, sw, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    got = dict(q.get(timeout=300) for _ in range(world))
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
-    for r in range(world):
-        assert got[r] == want, r
-
-
-def test_bench_two_ranks_on_one_gpu_result_is_the_global_msm():
-    """bench.py's N = 2 path on one GPU (OZK_BENCH_REHEARSAL=1: gloo instead of RCCL): the contract line, and
-    the printed result equals (sum over BOTH ranks' inputs of s_i k_i) G — bench.py's bases are k_i G with
-    k_i = splitmix64(seed + i), so the expected point is exact integer arithmetic plus one scalar multiplication."""
-    from octopuszk_amd import device as dev
-    logn = 12
-    env = dict(os.environ, OZK_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4",
-           "--warmup", "1", "--logn", str(logn)]
-    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and d["unit"] == "Mscalar-mul/s"
-    assert d["value"] > 0 and d["cpu_baseline"] is None and d["roofline"]["bound"] == "hbm"
-    assert "x2" in d["config"]["parallelism"]
-    n = 1 << logn
-    sys.path.insert(0, ROOT)
-    import bench
-    acc = 0
-    for rank in range(2):
-        ks = dev.gen_base_logs(n, bench.base_seed(rank))
-        sc = bench.rand_scalars(n, bench.scalar_seed(rank)).reshape(n, 32)
-        acc += sum(k * int.from_bytes(s.tobytes(), "little") for k, s in zip(ks, sc))
-    want = o.g1_out_le(o.G1.to_affine(o.G1.mul(o.G1.one, acc % o.R)))
-    assert bytes.fromhex(d["config"]["result_hex"]) == want
+# The in-process tests come first: the multi-process ones below start three to five child processes on the same GPU,
+# and the one unexplained failure of the round happened in the first in-process test run right
+# after them.
 
 
 @pytest.mark.parametrize("type_,n,shards", [(1, 5001, 3), (1, 4, 8), (2, 301, 2), (1, 70000, 4)])
@@ -217,3 +168,57 @@ def test_double_msm_host_sliced_equals_two_single_calls(n, min_log, monkeypatch)
         lib.check(L.ozk_tuning_reload())
     assert bytes(dbl1) == bytes(one1) + bytes(one2)
     assert bytes(dbl4) == bytes(dbl1)
+
+
+@pytest.mark.parametrize("n,world", [(4096, 2), (5001, 3)])
+def test_sharded_g1_msm_equals_oracle_on_the_whole_input(n, world):
+    rng = np.random.default_rng(n)
+    G = o.G1
+    pts = [G.to_affine(G.mul(G.one, int(k))) for k in rng.integers(1, 1 << 62, size=64)]
+    bw = b"".join(o.g1_to_wire(pts[i % 64]) for i in range(n))
+    sc = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    sc[:, 31] &= 0x1F
+    sw = sc.tobytes()
+    want = coracle.pippenger_g1(bw, sw, n)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, 1, bw, sw, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert got[r] == want, r
+
+
+def test_bench_two_ranks_on_one_gpu_result_is_the_global_msm():
+    """bench.py's N = 2 path on one GPU (OZK_BENCH_REHEARSAL=1: gloo instead of RCCL): the contract line, and
+    the printed result equals (sum over BOTH ranks' inputs of s_i k_i) G — bench.py's bases are k_i G with
+    k_i = splitmix64(seed + i), so the expected point is exact integer arithmetic plus one scalar multiplication."""
+    from octopuszk_amd import device as dev
+    logn = 12
+    env = dict(os.environ, OZK_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4",
+           "--warmup", "1", "--logn", str(logn)]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and d["unit"] == "Mscalar-mul/s"
+    assert d["value"] > 0 and d["cpu_baseline"] is None and d["roofline"]["bound"] == "hbm"
+    assert "x2" in d["config"]["parallelism"]
+    n = 1 << logn
+    sys.path.insert(0, ROOT)
+    import bench
+    acc = 0
+    for rank in range(2):
+        ks = dev.gen_base_logs(n, bench.base_seed(rank))
+        sc = bench.rand_scalars(n, bench.scalar_seed(rank)).reshape(n, 32)
+        acc += sum(k * int.from_bytes(s.tobytes(), "little") for k, s in zip(ks, sc))
+    want = o.g1_out_le(o.G1.to_affine(o.G1.mul(o.G1.one, acc % o.R)))
+    assert bytes.fromhex(d["config"]["result_hex"]) == want
