@@ -122,6 +122,52 @@ static MsmPlan make_plan(int n) {
   return p;
 }
 
+// The plan for a curve.  G2's level-1 kernel keeps its accumulators in LDS (72 KiB per workgroup): two workgroups per
+// CU, 512 on the chip, all doing the same amount of work — so the number of workgroups should be just under a multiple
+// of 512.  With the default chunk of 56 entries a 2^20 MSM is 1171 workgroups = 2.29 rounds, the last of which runs
+// on a third of the chip; 64 entries make it 1024 (two rounds: 7.34-7.39 -> 7.0-7.14 ms on two boxes), 128 make it 512
+// (one round: the same); 2^19: 5.35 -> 4.86 ms, 2^21: 11.99 -> 11.13.
+// The chunk is raised (never lowered) to the next such size.  G1 (three workgroups of 124 registers per CU, waves
+// that speed up when their SIMD empties) measured best at the default and keeps it.  OZK_MSM_L1 overrides both.
+// A LONE G1 MSM (the single-call entry points: nothing runs beside its level-1 kernel) gains from the same rule with
+// its three workgroups per CU: 2^20 = 1171 workgroups of 56 entries = 1.52 rounds of 768; 86 entries make it 763 (one
+// round): single MSM 2.52 -> 2.44 ms — and 85 entries (771 workgroups, three too many) 2.75 ms.  In the three-stage
+// schedule a one-round launch leaves the tails and the next sort no workgroup slot until it ends (86: 628 against
+// 690-709 Mscalar-mul/s), so the staged entry points keep the default chunk.  The single-call entry points mark their
+// thread (LonePlan) for the duration of the call.
+static thread_local int g_lone_plan = 0;
+struct LonePlan {
+  int prev;
+  LonePlan() : prev(g_lone_plan) { g_lone_plan = 1; }
+  ~LonePlan() { g_lone_plan = prev; }
+};
+template <class CV>
+static MsmPlan plan_for(int n) {
+  MsmPlan p = make_plan(n);
+  if ((CV::LDS_ACC || g_lone_plan) && env_int("OZK_MSM_L1", 0) == 0 && env_int("OZK_MSM_L1_ROUNDS", 1) != 0) {
+    static int cu_count = 0;   // (benign race: every thread computes the same value)
+    if (cu_count == 0) {
+      int dev = 0, cus = 0;
+      if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+          cus > 0)
+        cu_count = cus;
+      else
+        cu_count = 256;
+    }
+    const int slots = (CV::LDS_ACC ? 2 : 3) * cu_count;   // workgroups resident at once
+    const long long cap = (long long)p.n * p.W;           // sorted entries (upper bound: zero digits are skipped)
+    const long long blocks = ((cap + p.L1 - 1) / p.L1 + 255) / 256;
+    long long rounds = blocks / slots > 0 ? blocks / slots : 1;
+    // at most two rounds (2^21: 128 entries per lane, 11.30 -> 11.13 ms against the four rounds of 64; one round of
+    // 256 measures the same); OZK_MSM_L1_ROUNDS=0 switches the rule off, 1 asks for a single round
+    const long long max_rounds = env_int("OZK_MSM_L1_ROUNDS", 2);
+    if (rounds > max_rounds) rounds = max_rounds;
+    long long l1 = (cap + 256LL * slots * rounds - 1) / (256LL * slots * rounds);
+    if (l1 > p.L1 && l1 <= 1024) p.L1 = (int)l1;
+  }
+  return p;
+}
+
 struct MsmLayout {
   // all device pointers into the workspace
   u32* aff;
@@ -207,7 +253,7 @@ MsmLayout make_layout3(const MsmPlan& p, void* sorted, void* sort_ws, void* accu
 template <class CV>
 RegionBytes region_bytes(int n) {
   RegionBytes rb;
-  make_layout3<CV>(make_plan(n), nullptr, nullptr, nullptr, &rb);
+  make_layout3<CV>(plan_for<CV>(n), nullptr, nullptr, nullptr, &rb);
   return rb;
 }
 
@@ -299,7 +345,7 @@ template <class CV>
 int var_msm_sort(const void* d_bases, const void* d_scalars, int n, void* sorted, size_t sorted_bytes,
                         void* sort_ws, size_t sort_ws_bytes, hipStream_t st, hipEvent_t order_ev = nullptr,
                         const void* prepared = nullptr) {
-  const MsmPlan p = make_plan(n);
+  const MsmPlan p = plan_for<CV>(n);
   if (prepared && p.glv && !p.sd) return fail(OZK_E_INVALID, "prepared bases need the signed-digit plan");
   RegionBytes rb;
   const MsmLayout L = make_layout3<CV>(p, sorted, sort_ws, nullptr, &rb, prepared);
@@ -369,7 +415,7 @@ template <class CV>
 int var_msm_accum(int n, void* sorted, size_t sorted_bytes, void* accum_ws, size_t accum_ws_bytes, void* tail,
                          size_t tail_bytes, hipStream_t st, const void* prepared = nullptr) {
   using CT = CV;  // (an out-of-line-multiplication variant for the tails measured 40 % slower)
-  const MsmPlan p = make_plan(n);
+  const MsmPlan p = plan_for<CV>(n);
   RegionBytes rb;
   MsmLayout L = make_layout3<CV>(p, sorted, nullptr, accum_ws, &rb, prepared);
   if (rb.sorted > sorted_bytes || rb.accum_ws > accum_ws_bytes)
@@ -469,7 +515,7 @@ template <class CV>
 int var_msm_tail(int n, void* tail, size_t tail_bytes, void* d_out, hipStream_t st,
                         hipEvent_t order_ev = nullptr, int mode = TAIL_LATENCY) {
   using CT = CV;
-  MsmPlan p = make_plan(n);
+  MsmPlan p = plan_for<CV>(n);
   MsmLayout L;
   L.m1 = (((size_t)1 << p.cb) + p.S - 1) / p.S;
   const size_t tneed = tail_layout<CV>(p, L, tail, tail_bytes);
@@ -531,7 +577,7 @@ int var_msm_tail(int n, void* tail, size_t tail_bytes, void* d_out, hipStream_t 
 
 template <class CV>
 size_t var_msm_tail_bytes(int n) {
-  const MsmPlan p = make_plan(n);
+  const MsmPlan p = plan_for<CV>(n);
   MsmLayout L;
   L.m1 = (((size_t)1 << p.cb) + p.S - 1) / p.S;
   return tail_layout<CV>(p, L, nullptr, 0);
@@ -541,6 +587,7 @@ size_t var_msm_tail_bytes(int n) {
 template <class CV>
 int var_msm_dev(const void* d_bases, const void* d_scalars, int n, void* d_out, void* ws,
                        size_t ws_bytes, hipStream_t st, const void* prepared = nullptr) {
+  LonePlan lone;   // (before any size is computed: the lone plan's regions are never larger than the staged plan's)
   const RegionBytes rb0 = region_bytes<CV>(n);
   const size_t main_bytes = rb0.sorted + rb0.sort_ws + rb0.accum_ws;
   const size_t tb = var_msm_tail_bytes<CV>(n);
@@ -629,7 +676,7 @@ int host_sliced_msm(HostCtx* c, const uint8_t* bases, const uint8_t* scalars, in
     if (scalars) OZK_HIP(hipMemsetAsync(d_sc + (size_t)n * 32, 0, (padded - n) * 32, up));
     OZK_HIP(hipMemsetAsync(d_bases + (size_t)n * base_rec, 0, (padded - n) * base_rec, up));  // Z = 0: infinity
   }
-  const MsmPlan p = make_plan(per);
+  const MsmPlan p = plan_for<CV>(per);
   SliceBuckets sb = {};
   for (int s = 0; s < K; s++) {
     const size_t lo = (size_t)s * per;
@@ -696,7 +743,7 @@ int var_msm_host(const uint8_t* bases, const uint8_t* scalars, int n, int task_i
 // re-uploads it for every proof (VariableBaseMSM.java:224-227).
 template <class CV>
 size_t prepared_bytes(int n) {
-  const MsmPlan p = make_plan(n);
+  const MsmPlan p = plan_for<CV>(n);
   return (((size_t)p.n * CurveIO<CV>::AFF_WORDS * sizeof(u32)) + 255) & ~(size_t)255;
 }
 template <class CV>
