@@ -602,6 +602,8 @@ class _G1Pipeline:
         self.tail_bytes = max(int(L.ozk_var_msm_tail_bytes(n, 1)) for n in sizes)
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device="cuda")
         self.tails = [torch.empty(self.tail_bytes, dtype=torch.uint8, device="cuda") for _ in range(depth)]
+        self.full_ws_bytes = max(int(L.ozk_var_msm_workspace_bytes(n, 1)) for n in sizes)
+        self.full_ws = torch.empty(self.full_ws_bytes, dtype=torch.uint8, device="cuda")   # for submit(last=True)
         self.side = torch.cuda.Stream()
         self.head_done = [torch.cuda.Event() for _ in range(depth)]
         self.tail_done = [torch.cuda.Event() for _ in range(depth)]
@@ -612,13 +614,23 @@ class _G1Pipeline:
             self.levels_done.append(ev)
         self.count = 0
 
-    def submit(self, d_prepared, d_scalars, n, out):
-        """out: uint8[192] tensor that receives the result (valid once the returned event has fired)."""
+    def submit(self, d_prepared, d_scalars, n, out, last=False):
+        """out: uint8[192] tensor that receives the result (valid once the returned event has fired).
+        last=True: nothing follows this MSM in the pipeline, so most of its bucket accumulation and all of its tail
+        run with the chip to themselves — the single-call entry point then does better than head + tail: its level-1
+        launch is a whole number of rounds of the chip and its tail has the latency shape (a 2^20-constraint proof's H
+        MSM: 2.49 + 0.22 + 1.1 ms -> see DESIGN.md section 8)."""
         L = _lib.load()
         slot = self.count % self.depth
         main = torch.cuda.current_stream()
         if self.count >= self.depth:
             main.wait_event(self.tail_done[slot])
+        if last and os.environ.get("OZK_PROVER_LAST_LONE", "1") != "0":
+            _lib.check(L.ozk_var_msm_prepared_dev(_ptr(d_prepared), _ptr(d_scalars), n, 1, _ptr(out), _ptr(self.full_ws),
+                                                  self.full_ws_bytes, int(main.cuda_stream)))
+            self.tail_done[slot].record(main)
+            self.count += 1
+            return self.tail_done[slot]
         prev = self.levels_done[(self.count - 1) % self.depth] if self.count else None
         _lib.check(L.ozk_var_msm_head_prepared_dev(_ptr(d_prepared), _ptr(d_scalars), n, 1, _ptr(self.ws), self.ws_bytes,
                                                    _ptr(self.tails[slot]), self.tail_bytes, int(main.cuda_stream), prev))
@@ -762,7 +774,7 @@ class SerialProver:
         self.s_fin.wait_event(ev_b)
         ev_l = p.submit(self.dabc, d_aux, nw, o1[2])             # :98-101 deltaABC
         main.wait_event(h_ready)
-        ev_h = p.submit(self.qh, self.d_h, m + 1, o1[3])         # :91-93 query H
+        ev_h = p.submit(self.qh, self.d_h, m + 1, o1[3], last=True)   # :91-93 query H
         with torch.cuda.stream(self.s_fin):
             fin_bases = torch.cat((wire_out_to_in(o1[0], 1), wire_out_to_in(o1[1], 1), pk.delta_g1))
             _lib.check(L.ozk_var_msm_dev(_ptr(fin_bases), _ptr(d_fin_sc), 3, 1, _ptr(o1[4]), _ptr(self.fin_ws),
