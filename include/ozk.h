@@ -87,6 +87,20 @@ int ozk_var_msm_sharded_host(const uint8_t* bases, const uint8_t* scalars, int32
                              uint8_t* out);
 int ozk_var_msm_auto_host(const uint8_t* bases, const uint8_t* scalars, int32_t n, int32_t type, int32_t task_id,
                           uint8_t* out);
+/* The double MSM the same way (VariableBaseMSM.distributedDoubleMSM, VariableBaseMSM.java:805-818: per-partition
+ * doubleMSM + reduce(add)): out = 576 B, G1 (192) || G2 (384); ozk_var_double_msm_auto_host is what the JNI native
+ * calls (ozk_var_double_msm_host unless OZK_SHARD=1, as above). */
+int ozk_var_double_msm_sharded_host(const uint8_t* bases_g1, const uint8_t* bases_g2, const uint8_t* scalars, int32_t n,
+                                    int32_t shards, uint8_t* out);
+int ozk_var_double_msm_auto_host(const uint8_t* bases_g1, const uint8_t* bases_g2, const uint8_t* scalars, int32_t n,
+                                 int32_t task_id, uint8_t* out);
+/* The partial results of a sharded call meet through an RCCL all-gather over xGMI (communicators made once per process
+ * by ncclCommInitAll over the devices in use; librccl is bound at run time) followed by a HIP point sum on device 0 —
+ * or, when RCCL is absent, fails to initialise, is busy with another sharded call or OZK_SHARD_RCCL=0, through the
+ * host.  Same bytes either way.  ozk_shard_last_exchange(): how the calling thread's last sharded call did it
+ * (1 = RCCL, 0 = host, -1 = a single shard / no call yet).  ozk_shard_comms_release() drops the communicators. */
+int ozk_shard_last_exchange(void);
+void ozk_shard_comms_release(void);
 
 /* Device-resident variants.  `workspace` must hold ozk_var_msm_workspace_bytes(n, type)
  * bytes; all pointers are device pointers; `stream` is a hipStream_t (NULL = default). */

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libozk_hip.so")
 
 HIP_SOURCES = ["msm_var.hip", "msm_var_g2.hip", "msm_fixed.hip", "fft.hip", "host_ctx.hip"]
-HEADERS = ["consts_gen.h", "mad_chain_gen.h", "fp29.cuh", "fq2.cuh", "ec.cuh", "quad.cuh", "curve.cuh", "msm_var.cuh", "msm_var_driver.cuh", "glv.cuh", "ozk_common.h", "host_ctx.h",
+HEADERS = ["consts_gen.h", "mad_chain_gen.h", "fp29.cuh", "fq2.cuh", "ec.cuh", "quad.cuh", "curve.cuh", "msm_var.cuh", "msm_var_driver.cuh", "glv.cuh", "ozk_common.h", "host_ctx.h", "pin_cache.h",
            os.path.join("..", "..", "include", "ozk.h")]
 JNI_LIBS = {
     "libAlgebraMSMVariableBaseMSM.so": "jni_var_msm.c",

@@ -23,6 +23,7 @@
 
 #include "curve.cuh"
 #include "host_ctx.h"
+#include "pin_cache.h"
 
 namespace ozk {
 
@@ -476,6 +477,7 @@ static void fft_build_twiddles(const u32* d_omega, int n, u32* small, u32* tw, h
 // through the two ping-pong buffers (d_out may be one of them only if it is not read by the last pass)
 static int fft_core(const u32* d_in, int n, const u32* tw, u32* d_out, int out_stride, u32* buf0, u32* buf1,
                     hipStream_t st, const u32* scale = nullptr) {
+  hip_clear_stale();   // (ozk_common.h: a stale error of the calling thread is not this call's)
   const int logn = ilog2((uint32_t)n);
   if (n < FFT_TILE_SMALL) {
     if (scale) return fail(OZK_E_INTERNAL, "output scaling needs the tiled transform");
@@ -583,55 +585,54 @@ static int fft_core(const u32* d_in, int n, const u32* tw, u32* d_out, int out_s
 // When every plan of a device is pinned the cache grows past four and shrinks again on release.
 // OZK_FFT_PLAN_CACHE=0 builds the tables per call in the caller's workspace, as round 1 did.
 struct QapConsts;
-struct FftPlan {
-  int device = -1, n = 0;
+struct FftPlan : PinCacheItem {
+  int n = 0;
   bool qap = false;
-  uint8_t omega[32], g[32];
+  uint8_t omega[32] = {0}, g[32] = {0};
   uint8_t* mem = nullptr;
   u32 *tw_f = nullptr, *tw_i = nullptr, *pw_g = nullptr, *pw_gi = nullptr, *small = nullptr;
   u32 *sc_g = nullptr, *sc_gi = nullptr;
   QapConsts* consts = nullptr;
   hipEvent_t ready = nullptr;
-  unsigned long long last_use = 0;
-  int refs = 0;  // callers between plan_get and plan_release
+  bool same_key(const FftPlan& o) const {
+    return n == o.n && qap == o.qap && memcmp(omega, o.omega, 32) == 0 && (!qap || memcmp(g, o.g, 32) == 0);
+  }
 };
+// Round 4: the bookkeeping is pin_cache.h's — a plan is allocated, built and freed with NO lock held (round 3 held
+// one process-wide mutex across the hipMalloc, the build enqueue and an evicted plan's device-synchronising hipFree).
 constexpr int FFT_PLANS = 4;  // per device
-static pthread_mutex_t g_plan_mu = PTHREAD_MUTEX_INITIALIZER;
-static std::vector<FftPlan*> g_plans;  // guarded by g_plan_mu
-static unsigned long long g_plan_clock = 0;
+static PinCache<FftPlan> g_plans;
+static PinCacheLimits plan_limits() {
+  long mb = env_int("OZK_FFT_PLAN_CACHE_MB", 4096);   // (a 2^26 witness-map plan is 4 GiB; larger domains build per call)
+  if (mb < 0) mb = 0;
+  return PinCacheLimits{FFT_PLANS, (size_t)mb << 20};
+}
 
-// (g_plan_mu held) releases the plan's device memory; the caller's current device is restored
-static void plan_free(FftPlan* p) {
+// (no lock held) releases the plans' device memory; the caller's current device is restored
+static void plans_free(std::vector<FftPlan*>& dead) {
+  if (dead.empty()) return;
   int cur = 0;
   const bool have_cur = hipGetDevice(&cur) == hipSuccess;
-  if (p->mem) {
-    hipSetDevice(p->device);
-    hipFree(p->mem);
+  for (FftPlan* p : dead) {
+    if (p->mem) {
+      (void)hipSetDevice(p->device);
+      (void)hipFree(p->mem);
+    }
+    if (p->ready) (void)hipEventDestroy(p->ready);
+    delete p;
   }
-  if (p->ready) hipEventDestroy(p->ready);
-  if (have_cur) hipSetDevice(cur);
-  delete p;
+  dead.clear();
+  if (have_cur) (void)hipSetDevice(cur);
 }
 
 // returns the cached plan for (current device, n, omega[, g]), PINNED, with its build enqueued on `st` if it is
-// new; the caller releases it (plan_release / PlanPin) after enqueueing the last kernel that reads the tables
+// new; the caller releases it (plan_release / PlanPin) after enqueueing the last kernel that reads the tables.
+// *out stays null when the plan does not fit the cache's byte budget: the caller builds its tables per call.
 static int plan_get(int n, const uint8_t* omega, const uint8_t* g, hipStream_t st, FftPlan** out);
 static void plan_release(FftPlan* p) {
-  pthread_mutex_lock(&g_plan_mu);
-  p->refs--;
-  // a cache that had to grow because every plan was pinned shrinks back here
-  int on_dev = 0;
-  for (FftPlan* q : g_plans) on_dev += q->device == p->device;
-  if (on_dev > FFT_PLANS && p->refs == 0) {
-    FftPlan* victim = nullptr;
-    for (FftPlan* q : g_plans)
-      if (q->device == p->device && q->refs == 0 && (!victim || q->last_use < victim->last_use)) victim = q;
-    if (victim) {
-      g_plans.erase(std::find(g_plans.begin(), g_plans.end(), victim));
-      plan_free(victim);
-    }
-  }
-  pthread_mutex_unlock(&g_plan_mu);
+  std::vector<FftPlan*> dead;
+  g_plans.release(p, plan_limits(), &dead);
+  plans_free(dead);
 }
 struct PlanPin {
   FftPlan* p = nullptr;
@@ -648,7 +649,8 @@ static int fft_dev(const void* d_in, int n, const uint8_t* omega_host, void* d_o
     PlanPin pin;
     int rc = plan_get(n, omega_host, nullptr, st, &pin.p);
     if (rc) return rc;
-    return fft_core((const u32*)d_in, n, pin.p->tw_f, (u32*)d_out, out_stride, L.buf[0], L.buf[1], st);
+    if (pin.p) return fft_core((const u32*)d_in, n, pin.p->tw_f, (u32*)d_out, out_stride, L.buf[0], L.buf[1], st);
+    // (the plan does not fit the cache's byte budget: tables in the caller's workspace, below)
   }
   OZK_HIP(hipMemcpyAsync(L.omega, omega_host, 32, hipMemcpyHostToDevice, st));
   fft_build_twiddles(L.omega, n, L.small, L.tw, st);
@@ -806,6 +808,7 @@ static QapLayout qap_layout(int m, void* wsp, size_t wsb) {
 // the domain-dependent part of the witness map: constants, both twiddle tables, both coset power tables
 static int qap_build_tables(QapConsts* consts, u32* small, u32* tw_f, u32* tw_i, u32* pw_g, u32* pw_gi, u32* sc_g,
                             u32* sc_gi, int m, const uint8_t* omega_host, const uint8_t* g_host, hipStream_t st) {
+  hip_clear_stale();   // (ozk_common.h: a stale error of the calling thread is not this call's)
   OZK_HIP(hipMemcpyAsync(consts->omega, omega_host, 32, hipMemcpyHostToDevice, st));
   OZK_HIP(hipMemcpyAsync(consts->g, g_host, 32, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(k_qap_consts, dim3(4), dim3(64), 0, st, consts, m);
@@ -821,109 +824,99 @@ static int qap_build_tables(QapConsts* consts, u32* small, u32* tw_f, u32* tw_i,
 }
 
 static int plan_get(int n, const uint8_t* omega, const uint8_t* g, hipStream_t st, FftPlan** out) {
-  int dev = 0;
-  OZK_HIP(hipGetDevice(&dev));
-  pthread_mutex_lock(&g_plan_mu);
-  FftPlan* hit = nullptr;
-  FftPlan* victim = nullptr;  // least recently used UNPINNED plan of this device
-  int on_dev = 0;
-  for (FftPlan* p : g_plans) {
-    if (p->device != dev) continue;
-    on_dev++;
-    if (p->n == n && p->qap == (g != nullptr) && memcmp(p->omega, omega, 32) == 0 && (!g || memcmp(p->g, g, 32) == 0)) {
-      hit = p;
-      break;
+  *out = nullptr;
+  FftPlan key;
+  OZK_HIP(hipGetDevice(&key.device));
+  key.n = n;
+  key.qap = g != nullptr;
+  memcpy(key.omega, omega, 32);
+  if (g) memcpy(key.g, g, 32);
+  const int half = n / 2 > 0 ? n / 2 : 1;
+  const int hi = (n + TW_LO - 1) / TW_LO + 1;
+  auto carve = [&](uint8_t* base, FftPlan* dst) {   // same order with and without memory: sizes, then pointers
+    Bump b(base, ~(size_t)0);
+    QapConsts* c = b.take<QapConsts>(1);
+    u32* sm = b.take<u32>((size_t)(TW_LO + hi) * 8);
+    u32* twf = b.take<u32>((size_t)half * 8);
+    u32* twi = g ? b.take<u32>((size_t)half * 8) : nullptr;
+    u32* pg = g ? b.take<u32>((size_t)(TW_LO + hi) * 8) : nullptr;
+    u32* pgi = g ? b.take<u32>((size_t)(TW_LO + hi) * 8) : nullptr;
+    u32* sg = g ? b.take<u32>((size_t)n * 8) : nullptr;
+    u32* sgi = g ? b.take<u32>((size_t)n * 8) : nullptr;
+    b.take<u32>(64);
+    if (dst) {
+      dst->sc_g = sg;
+      dst->sc_gi = sgi;
+      dst->consts = c;
+      dst->small = sm;
+      dst->tw_f = twf;
+      dst->tw_i = twi;
+      dst->pw_g = pg;
+      dst->pw_gi = pgi;
     }
-    if (p->refs == 0 && (!victim || p->last_use < victim->last_use)) victim = p;
-  }
-  int rc = OZK_OK;
-  if (!hit) {
-    if (on_dev >= FFT_PLANS && victim) {  // (all pinned: grow; plan_release shrinks the cache again)
-      g_plans.erase(std::find(g_plans.begin(), g_plans.end(), victim));
-      plan_free(victim);
-    }
-    FftPlan* np = new (std::nothrow) FftPlan();
-    if (!np) {
-      pthread_mutex_unlock(&g_plan_mu);
-      return fail(OZK_E_NOMEM, "out of host memory");
-    }
-    FftPlan& p = *np;
-    p.device = dev;
-    p.n = n;
-    p.qap = g != nullptr;
-    memcpy(p.omega, omega, 32);
-    if (g) memcpy(p.g, g, 32);
-    const int half = n / 2 > 0 ? n / 2 : 1;
-    const int hi = (n + TW_LO - 1) / TW_LO + 1;
-    auto carve = [&](uint8_t* base, FftPlan* dst) {   // same order with and without memory: sizes, then pointers
-      Bump b(base, ~(size_t)0);
-      QapConsts* c = b.take<QapConsts>(1);
-      u32* sm = b.take<u32>((size_t)(TW_LO + hi) * 8);
-      u32* twf = b.take<u32>((size_t)half * 8);
-      u32* twi = g ? b.take<u32>((size_t)half * 8) : nullptr;
-      u32* pg = g ? b.take<u32>((size_t)(TW_LO + hi) * 8) : nullptr;
-      u32* pgi = g ? b.take<u32>((size_t)(TW_LO + hi) * 8) : nullptr;
-      u32* sg = g ? b.take<u32>((size_t)n * 8) : nullptr;
-      u32* sgi = g ? b.take<u32>((size_t)n * 8) : nullptr;
-      b.take<u32>(64);
-      if (dst) {
-        dst->sc_g = sg;
-        dst->sc_gi = sgi;
-        dst->consts = c;
-        dst->small = sm;
-        dst->tw_f = twf;
-        dst->tw_i = twi;
-        dst->pw_g = pg;
-        dst->pw_gi = pgi;
+    return b.off;
+  };
+  const size_t bytes = carve(nullptr, nullptr);
+  std::vector<FftPlan*> dead;
+  FftPlan* p = nullptr;
+  const auto res = g_plans.acquire(
+      key, bytes, plan_limits(), false,
+      [&]() -> FftPlan* {
+        FftPlan* np = new (std::nothrow) FftPlan();
+        if (np) {
+          np->device = key.device;
+          np->n = key.n;
+          np->qap = key.qap;
+          memcpy(np->omega, key.omega, 32);
+          memcpy(np->g, key.g, 32);
+        }
+        return np;
+      },
+      &p, &dead);
+  plans_free(dead);   // evicted plans: hipFree outside the cache's lock
+  if (res == PinCache<FftPlan>::PER_CALL) return OZK_OK;
+  if (res == PinCache<FftPlan>::BUILD_FAILED) return fail(OZK_E_NOMEM, "FFT plan could not be built (host memory, or a concurrent build of the same plan failed)");
+  if (res == PinCache<FftPlan>::BUILD) {
+    int rc = OZK_OK;
+    hipError_t e = hipMalloc((void**)&p->mem, bytes);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ready, hipEventDisableTiming);
+    if (e != hipSuccess) rc = fail(OZK_E_NOMEM, "FFT plan allocation (%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    if (!rc) {
+      carve(p->mem, p);
+      if (g) {
+        rc = qap_build_tables(p->consts, p->small, p->tw_f, p->tw_i, p->pw_g, p->pw_gi, p->sc_g, p->sc_gi, n, omega, g, st);
+      } else {
+        // (from the plan's own copy of omega: host memory that outlives the asynchronous copy)
+        hipError_t e2 = hipMemcpyAsync(p->consts->omega, p->omega, 32, hipMemcpyHostToDevice, st);
+        if (e2 != hipSuccess) rc = fail(OZK_E_NO_DEVICE, "hipMemcpyAsync failed: %s", hipGetErrorString(e2));
+        else fft_build_twiddles(p->consts->omega, n, p->small, p->tw_f, st);
       }
-      return b.off;
-    };
-    const size_t bytes = carve(nullptr, nullptr);
-    hipError_t e = hipMalloc((void**)&p.mem, bytes);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&p.ready, hipEventDisableTiming);
-    if (e != hipSuccess) {
-      plan_free(np);
-      pthread_mutex_unlock(&g_plan_mu);
-      return fail(OZK_E_NOMEM, "FFT plan allocation (%zu bytes) failed: %s", bytes, hipGetErrorString(e));
     }
-    carve(p.mem, &p);
-    if (g) {
-      rc = qap_build_tables(p.consts, p.small, p.tw_f, p.tw_i, p.pw_g, p.pw_gi, p.sc_g, p.sc_gi, n, omega, g, st);
-    } else {
-      hipError_t e2 = hipMemcpyAsync(p.consts->omega, omega, 32, hipMemcpyHostToDevice, st);
-      if (e2 != hipSuccess) rc = fail(OZK_E_NO_DEVICE, "hipMemcpyAsync failed: %s", hipGetErrorString(e2));
-      else fft_build_twiddles(p.consts->omega, n, p.small, p.tw_f, st);
-    }
-    if (!rc && hipEventRecord(p.ready, st) != hipSuccess) rc = fail(OZK_E_NO_DEVICE, "hipEventRecord failed");
-    if (rc) {
-      plan_free(np);
-      pthread_mutex_unlock(&g_plan_mu);
-      return rc;
-    }
-    g_plans.push_back(np);
-    hit = np;
+    if (!rc && hipEventRecord(p->ready, st) != hipSuccess) rc = fail(OZK_E_NO_DEVICE, "hipEventRecord failed");
+    g_plans.publish(p, rc == OZK_OK, &dead);
+    plans_free(dead);
+    if (rc) return rc;
   }
-  hit->last_use = ++g_plan_clock;
-  hit->refs++;
-  hipEvent_t ev = hit->ready;
-  pthread_mutex_unlock(&g_plan_mu);
-  const hipError_t we = hipStreamWaitEvent(st, ev, 0);   // a no-op on the stream that built it
+  const hipError_t we = hipStreamWaitEvent(st, p->ready, 0);   // a no-op on the stream that built it
   if (we != hipSuccess) {
-    plan_release(hit);
+    plan_release(p);
     return fail(OZK_E_NO_DEVICE, "hipStreamWaitEvent failed: %s", hipGetErrorString(we));
   }
-  *out = hit;
+  *out = p;
   return OZK_OK;
 }
 
 static int qap_witness_dev(const void* d_A, const void* d_B, const void* d_C, int m, const uint8_t* omega_host,
                            const uint8_t* g_host, void* d_H, void* wsp, size_t wsb, hipStream_t st) {
+  hip_clear_stale();   // (ozk_common.h: a stale error of the calling thread is not this call's)
   QapLayout L = qap_layout(m, wsp, wsb);
   if (L.bytes > wsb) return fail(OZK_E_INVALID, "workspace too small: need %zu bytes, got %zu", L.bytes, wsb);
   PlanPin pin;  // held until the last launch below is enqueued
   if (env_int("OZK_FFT_PLAN_CACHE", 1)) {
     int prc = plan_get(m, omega_host, g_host, st, &pin.p);
     if (prc) return prc;
+  }
+  if (pin.p) {   // (else: cache off, or the plan does not fit its byte budget — tables in the workspace)
     FftPlan* pl = pin.p;
     L.consts = pl->consts;
     L.tw_f = pl->tw_f;
@@ -1211,16 +1204,9 @@ using namespace ozk;
 
 namespace ozk {
 void fft_plan_cache_release() {
-  pthread_mutex_lock(&g_plan_mu);
-  for (size_t i = 0; i < g_plans.size();) {  // pinned plans (a call in flight on another thread) stay
-    if (g_plans[i]->refs == 0) {
-      plan_free(g_plans[i]);
-      g_plans.erase(g_plans.begin() + (long)i);
-    } else {
-      i++;
-    }
-  }
-  pthread_mutex_unlock(&g_plan_mu);
+  std::vector<FftPlan*> dead;
+  g_plans.drain(&dead);   // pinned plans (a call in flight on another thread) stay
+  plans_free(dead);
 }
 }  // namespace ozk
 
@@ -1270,6 +1256,7 @@ size_t ozk_r1cs_evaluate_workspace_bytes(int32_t n_long) {
 int ozk_r1cs_evaluate_dev(const void* d_row_ptr, const void* d_index, const void* d_coeff, const void* d_assignment,
                           int32_t rows, const void* d_long_rows, int32_t n_long, void* d_out, void* d_workspace,
                           size_t workspace_bytes, void* stream) {
+  hip_clear_stale();   // (ozk_common.h: a stale error of the calling thread is not this call's)
   if (!d_row_ptr || !d_index || !d_assignment || !d_out || (n_long > 0 && (!d_long_rows || !d_workspace)))
     return fail(OZK_E_INVALID, "null pointer argument");
   if (rows <= 0 || n_long < 0) return fail(OZK_E_INVALID, "bad row count");
@@ -1295,6 +1282,7 @@ int ozk_r1cs_evaluate_dev(const void* d_row_ptr, const void* d_index, const void
 int ozk_sparse_mat_vec_dev(const void* d_row_ptr, const void* d_index, const void* d_coeff, const void* d_vec,
                            int32_t rows, const void* d_long_rows, int32_t n_long, void* d_out, void* d_workspace,
                            size_t workspace_bytes, void* stream) {
+  hip_clear_stale();   // (ozk_common.h: a stale error of the calling thread is not this call's)
   if (!d_row_ptr || !d_index || !d_vec || !d_out || (n_long > 0 && (!d_long_rows || !d_workspace)))
     return fail(OZK_E_INVALID, "null pointer argument");
   if (rows <= 0 || n_long < 0) return fail(OZK_E_INVALID, "bad row count");
@@ -1317,8 +1305,8 @@ int ozk_sparse_mat_vec_dev(const void* d_row_ptr, const void* d_index, const voi
 
 // Lagrange coefficients of the radix-2 domain of size m at t (FFTAuxiliary.java:250-302) and Z(t) = t^m - 1.
 // d_out: m x 32 B plain LE; d_zt: 32 B; workspace: ozk_qap_lagrange_workspace_bytes(m).  t must not be a domain
-// element (the caller tests t^m == 1 and takes the reference's indicator branch itself: it never happens for a
-// random t).  omega: the domain's root of unity.
+// element: the entry point computes t^m on the host and returns OZK_E_INVALID when it is 1 (the caller then takes the
+// reference's indicator branch itself: it never happens for a random t).  omega: the domain's root of unity.
 size_t ozk_qap_lagrange_workspace_bytes(int32_t m) {
   if (m <= 1 || (m & (m - 1))) return 0;
   const int hi = (m + TW_LO - 1) / TW_LO + 1;
@@ -1326,9 +1314,25 @@ size_t ozk_qap_lagrange_workspace_bytes(int32_t m) {
 }
 int ozk_qap_lagrange_dev(const uint8_t* t_host32, const uint8_t* omega_host32, int32_t m, void* d_out, void* d_zt,
                          void* d_workspace, size_t workspace_bytes, void* stream) {
+  hip_clear_stale();   // (ozk_common.h: a stale error of the calling thread is not this call's)
   if (!t_host32 || !omega_host32 || !d_out || !d_zt || !d_workspace) return fail(OZK_E_INVALID, "null pointer argument");
   if (m <= 1 || (m & (m - 1)) || m > (1 << 28)) return fail(OZK_E_INVALID, "domain size %d is not a power of two in [2, 2^28]", m);
   if (workspace_bytes < ozk_qap_lagrange_workspace_bytes(m)) return fail(OZK_E_INVALID, "workspace too small");
+  {
+    // t in the domain (t^m == 1) makes one denominator t - omega^i zero, and the shared inversion of its lane would
+    // silently zero all LAG_BATCH coefficients of that lane: refused here, on the host (log2 m squarings), so that a
+    // C-ABI / JNI caller that forgot the test gets an error instead of a wrong CRS.  The reference takes its
+    // indicator branch in that case (FFTAuxiliary.java:262-276); a caller does the same on its side.
+    u32 tw[8];
+    memcpy(tw, t_host32, 32);
+    Fe<FrP, 32> tm = Fe<FrP, 32>(to_mont<FrP>(tw));
+    for (int k = m; k > 1; k >>= 1) tm = Fe<FrP, 32>(sqr(tm));
+    u32 o[8], one[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+    from_mont(tm, o);
+    if (memcmp(o, one, 32) == 0)
+      return fail(OZK_E_INVALID, "t is an element of the size-%d domain (t^m = 1): the Lagrange coefficients are an indicator vector, "
+                                 "take that branch on the caller's side", m);
+  }
   hipStream_t st = (hipStream_t)stream;
   uint8_t* w = (uint8_t*)d_workspace;
   LagConsts* c = (LagConsts*)w;
@@ -1354,6 +1358,7 @@ size_t ozk_fr_powers_workspace_bytes(int32_t n) {
 }
 int ozk_fr_powers_dev(const uint8_t* base_host32, const uint8_t* k_host32, int32_t n, void* d_out, void* d_workspace,
                       size_t workspace_bytes, void* stream) {
+  hip_clear_stale();   // (ozk_common.h: a stale error of the calling thread is not this call's)
   if (!base_host32 || !k_host32 || !d_out || !d_workspace) return fail(OZK_E_INVALID, "null pointer argument");
   if (n <= 0 || n > (1 << 28) + 1) return fail(OZK_E_INVALID, "count %d out of range", n);
   if (workspace_bytes < ozk_fr_powers_workspace_bytes(n)) return fail(OZK_E_INVALID, "workspace too small");
@@ -1374,6 +1379,7 @@ int ozk_fr_powers_dev(const uint8_t* base_host32, const uint8_t* k_host32, int32
 // ka, kb, kk: 32-byte LE host values; d_scratch: 96 bytes of device memory for the three constants.
 int ozk_fr_lincomb3_dev(const void* d_a, const void* d_b, const void* d_c, int32_t n, const uint8_t* ka_host32,
                         const uint8_t* kb_host32, const uint8_t* kk_host32, void* d_out, void* d_scratch96, void* stream) {
+  hip_clear_stale();   // (ozk_common.h: a stale error of the calling thread is not this call's)
   if (!d_a || !d_b || !d_c || !ka_host32 || !kb_host32 || !kk_host32 || !d_out || !d_scratch96)
     return fail(OZK_E_INVALID, "null pointer argument");
   if (n <= 0) return fail(OZK_E_INVALID, "count %d out of range", n);

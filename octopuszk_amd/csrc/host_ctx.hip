@@ -74,18 +74,36 @@ void copy_start_locked() {
 // native library, or a dlclose, must not leave threads sleeping in unmapped text).  Callers in flight finish their
 // own pieces (parallel_memcpy drains the queue itself); the next call starts new helpers.
 void copy_shutdown() {
+  // One shutdown at a time, and the thread ids leave the pool before anybody joins them: two concurrent
+  // ozk_host_cache_release calls (or a release racing the library destructor) used to join the same pthread_t
+  // twice — undefined behaviour.
+  static pthread_mutex_t shutdown_mu = PTHREAD_MUTEX_INITIALIZER;
+  pthread_mutex_lock(&shutdown_mu);
+  pthread_t th[COPY_HELPERS_MAX];
   pthread_mutex_lock(&g_copy.mu);
   const int n = g_copy.running;
+  for (int i = 0; i < n; i++) th[i] = g_copy.th[i];
+  g_copy.running = 0;
   g_copy.stop = true;
   pthread_cond_broadcast(&g_copy.cv);
   pthread_mutex_unlock(&g_copy.mu);
-  for (int i = 0; i < n; i++) pthread_join(g_copy.th[i], nullptr);
+  for (int i = 0; i < n; i++) pthread_join(th[i], nullptr);
   pthread_mutex_lock(&g_copy.mu);
-  g_copy.running = 0;
   g_copy.started = false;
   g_copy.failed = false;
   pthread_mutex_unlock(&g_copy.mu);
+  pthread_mutex_unlock(&shutdown_mu);
 }
+// A forked child has none of the helper threads (only the forking thread survives): its pool starts empty, so the
+// destructor's join is a no-op there instead of a wait for threads that do not exist.
+void copy_atfork_child() {
+  pthread_mutex_init(&g_copy.mu, nullptr);
+  pthread_cond_init(&g_copy.cv, nullptr);
+  g_copy.head = g_copy.count = 0;
+  g_copy.running = 0;
+  g_copy.started = g_copy.failed = g_copy.stop = false;
+}
+__attribute__((constructor)) void copy_register_atfork() { pthread_atfork(nullptr, nullptr, copy_atfork_child); }
 void parallel_memcpy(void* dst, const void* src, size_t len) {
   const int helpers = copy_helpers();
   if (len < ((size_t)1 << 20) || helpers <= 0) {
@@ -370,6 +388,7 @@ extern "C" int ozk_host_cache_release(void) {
   copy_shutdown();
   fft_plan_cache_release();
   fb_table_cache_release();
+  ozk_shard_comms_release();   // msm_var.hip: the sharded entry's RCCL communicators
   pthread_mutex_lock(&g_pool_mu);
   for (int d = 0; d < MAX_DEVICES; d++) {
     HostCtx* c = g_free[d];

@@ -12,7 +12,8 @@ JNIEXPORT jbyteArray JNICALL Java_algebra_msm_VariableBaseMSM_variableBaseSerial
   jbyte* s = ozk_borrow(env, scalars, 32LL * batch_size, "scalars");
   if (!s) { ozk_release(env, bases, b); return NULL; }
   uint8_t out[384];
-  /* one GPU (taskID % count), or all visible ones for a large call (include/ozk.h) */
+  /* one GPU (taskID % count), as the reference; OZK_SHARD=1 (opt-in) spreads calls of >= 2^21 pairs over the visible
+   * GPUs (include/ozk.h, ozk_var_msm_auto_host) */
   const int rc = ozk_var_msm_auto_host((const uint8_t*)b, (const uint8_t*)s, batch_size, type, taskID, out);
   ozk_release(env, scalars, s);
   ozk_release(env, bases, b);
@@ -32,8 +33,8 @@ JNIEXPORT jbyteArray JNICALL Java_algebra_msm_VariableBaseMSM_variableBaseDouble
   jbyte* s = ozk_borrow(env, scalars, 32LL * batch_size, "scalars");
   if (!s) { ozk_release(env, bases_g2, b2); ozk_release(env, bases_g1, b1); return NULL; }
   uint8_t out[576];
-  const int rc = ozk_var_double_msm_host((const uint8_t*)b1, (const uint8_t*)b2, (const uint8_t*)s, batch_size,
-                                         taskID, out);
+  const int rc = ozk_var_double_msm_auto_host((const uint8_t*)b1, (const uint8_t*)b2, (const uint8_t*)s, batch_size,
+                                              taskID, out);
   ozk_release(env, scalars, s);
   ozk_release(env, bases_g2, b2);
   ozk_release(env, bases_g1, b1);

@@ -32,6 +32,7 @@
 #include "glv.cuh"
 #include "msm_var.cuh"  // RunAccLds: the LDS-resident XYZZ accumulator (G2)
 #include "host_ctx.h"
+#include "pin_cache.h"
 
 namespace ozk {
 
@@ -421,6 +422,7 @@ static FbPlan fb_choose(int outerc, int ws, int n) {
 template <class CV>
 static int fb_build(const FbPlan& fp, int outerc, int ws, int n, const void* d_base, void* wsp, size_t wsb, hipStream_t st,
                     u32* aff = nullptr, u32* aff_phi = nullptr) {
+  hip_clear_stale();   // (ozk_common.h: a stale error of the calling thread is not this call's)
   using IO = CurveIO<CV>;
   const FbLayout L = fb_layout<CV>(outerc, ws, n, wsp, wsb);
   if (L.bytes > wsb) return fail(OZK_E_INVALID, "workspace too small: need %zu bytes, got %zu", L.bytes, wsb);
@@ -452,6 +454,7 @@ static int fb_table(int outerc, int ws, int n, const void* d_base, void* wsp, si
 template <class CV>
 static int fb_apply(const FbPlan& fp, int outerc, int ws, int n, int lo, int cnt, const void* d_scalars, void* d_out,
                     int out_stride_words, void* wsp, size_t wsb, hipStream_t st, int compact) {
+  hip_clear_stale();   // (ozk_common.h: a stale error of the calling thread is not this call's)
   using IO = CurveIO<CV>;
   const FbLayout L = fb_layout<CV>(outerc, ws, n, wsp, wsb);
   const int TB = 256;
@@ -494,46 +497,49 @@ static int fixed_batch_dev(int outerc, int ws, int n, const void* d_base, const 
 // affine table of the default (GLV) form is kept in library-owned HBM, keyed by (device, curve, outerc, windowSize,
 // chosen table window, base bytes): four per device, least recently used out, pinned while a caller is between
 // tab_get and its last launch — the FFT plan cache's rules (fft.hip).  OZK_FB_TABLE_CACHE=0: per-call tables.
-struct FbTab {
-  int device = -1, type = 0, outerc = 0, ws = 0, wt = 0, oc = 0;
-  uint8_t base[192];
+struct FbTab : PinCacheItem {
+  int type = 0, outerc = 0, ws = 0, wt = 0, oc = 0;
+  uint8_t base[192] = {0};
   uint8_t* mem = nullptr;
   u32 *aff = nullptr, *aff_phi = nullptr, *d_base = nullptr;
   hipEvent_t ready = nullptr;
-  unsigned long long last_use = 0;
-  int refs = 0;
+  bool same_key(const FbTab& o) const {
+    return type == o.type && outerc == o.outerc && ws == o.ws && wt == o.wt && oc == o.oc &&
+           memcmp(base, o.base, type == OZK_G1 ? 96 : 192) == 0;
+  }
 };
+// Round 4 (pin_cache.h): the table is allocated, built and freed with NO lock held (round 3 held one process-wide mutex
+// across a ~13 ms hipMalloc, the build enqueue and the evicted table's device-synchronising hipFree); a table is
+// cached from the SECOND call with its key on (the first leaves a marker and builds in the caller's workspace, as
+// before the cache existed), so a setup whose batches all differ in size pays nothing for tables nobody reuses;
+// and the tables of a device stay inside a byte budget (OZK_FB_TABLE_CACHE_MB, default 1024; four tables at most).
 constexpr int FB_TABS = 4;  // per device
-static pthread_mutex_t g_tab_mu = PTHREAD_MUTEX_INITIALIZER;
-static std::vector<FbTab*> g_tabs;  // guarded by g_tab_mu
-static unsigned long long g_tab_clock = 0;
-
-static void tab_free(FbTab* t) {   // (g_tab_mu held)
+static PinCache<FbTab> g_tabs;
+static PinCacheLimits tab_limits() {
+  long mb = env_int("OZK_FB_TABLE_CACHE_MB", 1024);
+  if (mb < 0) mb = 0;
+  return PinCacheLimits{FB_TABS, (size_t)mb << 20};
+}
+// (no lock held) releases the tables' device memory; the caller's current device is restored
+static void tabs_free(std::vector<FbTab*>& dead) {
+  if (dead.empty()) return;
   int cur = 0;
   const bool have_cur = hipGetDevice(&cur) == hipSuccess;
-  if (t->mem) {
-    (void)hipSetDevice(t->device);
-    (void)hipFree(t->mem);   // waits for the kernels already enqueued
+  for (FbTab* t : dead) {
+    if (t->mem) {
+      (void)hipSetDevice(t->device);
+      (void)hipFree(t->mem);   // waits for the kernels already enqueued
+    }
+    if (t->ready) (void)hipEventDestroy(t->ready);
+    delete t;
   }
-  if (t->ready) (void)hipEventDestroy(t->ready);
+  dead.clear();
   if (have_cur) (void)hipSetDevice(cur);
-  delete t;
 }
 static void tab_release(FbTab* t) {
-  pthread_mutex_lock(&g_tab_mu);
-  t->refs--;
-  int on_dev = 0;
-  for (FbTab* q : g_tabs) on_dev += q->device == t->device;
-  if (on_dev > FB_TABS && t->refs == 0) {   // a cache that grew because every table was pinned shrinks back
-    FbTab* victim = nullptr;
-    for (FbTab* q : g_tabs)
-      if (q->device == t->device && q->refs == 0 && (!victim || q->last_use < victim->last_use)) victim = q;
-    if (victim) {
-      g_tabs.erase(std::find(g_tabs.begin(), g_tabs.end(), victim));
-      tab_free(victim);
-    }
-  }
-  pthread_mutex_unlock(&g_tab_mu);
+  std::vector<FbTab*> dead;
+  g_tabs.release(t, tab_limits(), &dead);
+  tabs_free(dead);
 }
 struct TabPin {
   FbTab* t = nullptr;
@@ -542,97 +548,80 @@ struct TabPin {
   }
 };
 void fb_table_cache_release() {
-  pthread_mutex_lock(&g_tab_mu);
-  for (size_t i = 0; i < g_tabs.size();) {  // pinned tables (a call in flight on another thread) stay
-    if (g_tabs[i]->refs == 0) {
-      tab_free(g_tabs[i]);
-      g_tabs.erase(g_tabs.begin() + (long)i);
-    } else {
-      i++;
-    }
-  }
-  pthread_mutex_unlock(&g_tab_mu);
+  std::vector<FbTab*> dead;
+  g_tabs.drain(&dead);
+  tabs_free(dead);
 }
 
 // the cached affine table for (current device, curve, outerc, ws, fp.wt, base), PINNED, its build enqueued on `st`
-// (in the caller's workspace) if it is new; fp.aff / fp.aff_phi are set.  Only for fp.affine.
+// (in the caller's workspace) if it is new; fp.aff / fp.aff_phi are set.  Only for fp.affine.  *out stays null when
+// nothing is cached for this call (first sight of the key, or no room): the caller builds a per-call table.
 template <class CV>
 static int tab_get(FbPlan* fp, int outerc, int ws, int n, const uint8_t* base_host, void* wsp, size_t wsb, hipStream_t st,
                    FbTab** out) {
   using IO = CurveIO<CV>;
   constexpr int type = std::is_same<CV, G1Cfg>::value ? OZK_G1 : OZK_G2;
   constexpr size_t base_bytes = type == OZK_G1 ? 96 : 192;
-  int dev = 0;
-  OZK_HIP(hipGetDevice(&dev));
-  pthread_mutex_lock(&g_tab_mu);
-  FbTab* hit = nullptr;
-  FbTab* victim = nullptr;
-  int on_dev = 0;
-  for (FbTab* t : g_tabs) {
-    if (t->device != dev) continue;
-    on_dev++;
-    if (t->type == type && t->outerc == outerc && t->ws == ws && t->wt == fp->wt && t->oc == fp->oc &&
-        memcmp(t->base, base_host, base_bytes) == 0) {
-      hit = t;
-      break;
+  *out = nullptr;
+  FbTab key;
+  OZK_HIP(hipGetDevice(&key.device));
+  key.type = type;
+  key.outerc = outerc;
+  key.ws = ws;
+  key.wt = fp->wt;
+  key.oc = fp->oc;
+  memcpy(key.base, base_host, base_bytes);
+  const size_t entries = (size_t)fp->oc << fp->wt;
+  const size_t half = pad256(entries * IO::AFF_WORDS * 4);
+  const size_t bytes = 2 * half + 256;
+  std::vector<FbTab*> dead;
+  FbTab* t = nullptr;
+  const auto res = g_tabs.acquire(
+      key, bytes, tab_limits(), env_int("OZK_FB_TABLE_CACHE_SECOND_USE", 1) != 0,
+      [&]() -> FbTab* {
+        FbTab* nt = new (std::nothrow) FbTab();
+        if (nt) {
+          nt->device = key.device;
+          nt->type = key.type;
+          nt->outerc = key.outerc;
+          nt->ws = key.ws;
+          nt->wt = key.wt;
+          nt->oc = key.oc;
+          memcpy(nt->base, key.base, sizeof(key.base));
+        }
+        return nt;
+      },
+      &t, &dead);
+  tabs_free(dead);   // evicted tables: hipFree outside the cache's lock
+  if (res == PinCache<FbTab>::PER_CALL) return OZK_OK;
+  if (res == PinCache<FbTab>::BUILD_FAILED) return OZK_OK;   // (a concurrent build of this key failed: per-call table)
+  if (res == PinCache<FbTab>::BUILD) {
+    int rc = OZK_OK;
+    hipError_t e = hipMalloc((void**)&t->mem, bytes);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&t->ready, hipEventDisableTiming);
+    if (e != hipSuccess) rc = fail(OZK_E_NOMEM, "fixed-base table allocation (%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    if (!rc) {
+      t->aff = (u32*)t->mem;
+      t->aff_phi = (u32*)(t->mem + half);
+      t->d_base = (u32*)(t->mem + 2 * half);
+      // (from the table's own copy of the base: host memory that outlives the asynchronous copy)
+      e = hipMemcpyAsync(t->d_base, t->base, base_bytes, hipMemcpyHostToDevice, st);
+      if (e != hipSuccess) rc = fail(OZK_E_NO_DEVICE, "hipMemcpyAsync failed: %s", hipGetErrorString(e));
     }
-    if (t->refs == 0 && (!victim || t->last_use < victim->last_use)) victim = t;
+    if (!rc) rc = fb_build<CV>(*fp, outerc, ws, n, t->d_base, wsp, wsb, st, t->aff, t->aff_phi);
+    if (!rc && hipEventRecord(t->ready, st) != hipSuccess) rc = fail(OZK_E_NO_DEVICE, "hipEventRecord failed");
+    g_tabs.publish(t, rc == OZK_OK, &dead);
+    tabs_free(dead);
+    if (rc) return rc;
   }
-  int rc = OZK_OK;
-  if (!hit) {
-    if (on_dev >= FB_TABS && victim) {
-      g_tabs.erase(std::find(g_tabs.begin(), g_tabs.end(), victim));
-      tab_free(victim);
-    }
-    FbTab* nt = new (std::nothrow) FbTab();
-    if (!nt) {
-      pthread_mutex_unlock(&g_tab_mu);
-      return fail(OZK_E_NOMEM, "out of host memory");
-    }
-    nt->device = dev;
-    nt->type = type;
-    nt->outerc = outerc;
-    nt->ws = ws;
-    nt->wt = fp->wt;
-    nt->oc = fp->oc;
-    memcpy(nt->base, base_host, base_bytes);
-    const size_t entries = (size_t)fp->oc << fp->wt;
-    const size_t half = pad256(entries * IO::AFF_WORDS * 4);
-    hipError_t e = hipMalloc((void**)&nt->mem, 2 * half + 256);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&nt->ready, hipEventDisableTiming);
-    if (e != hipSuccess) {
-      tab_free(nt);
-      pthread_mutex_unlock(&g_tab_mu);
-      return fail(OZK_E_NOMEM, "fixed-base table allocation (%zu bytes) failed: %s", 2 * half + 256, hipGetErrorString(e));
-    }
-    nt->aff = (u32*)nt->mem;
-    nt->aff_phi = (u32*)(nt->mem + half);
-    nt->d_base = (u32*)(nt->mem + 2 * half);
-    // (from the table's own copy of the base: host memory that outlives the asynchronous copy)
-    e = hipMemcpyAsync(nt->d_base, nt->base, base_bytes, hipMemcpyHostToDevice, st);
-    if (e != hipSuccess) rc = fail(OZK_E_NO_DEVICE, "hipMemcpyAsync failed: %s", hipGetErrorString(e));
-    if (!rc) rc = fb_build<CV>(*fp, outerc, ws, n, nt->d_base, wsp, wsb, st, nt->aff, nt->aff_phi);
-    if (!rc && hipEventRecord(nt->ready, st) != hipSuccess) rc = fail(OZK_E_NO_DEVICE, "hipEventRecord failed");
-    if (rc) {
-      tab_free(nt);
-      pthread_mutex_unlock(&g_tab_mu);
-      return rc;
-    }
-    g_tabs.push_back(nt);
-    hit = nt;
-  }
-  hit->last_use = ++g_tab_clock;
-  hit->refs++;
-  hipEvent_t ev = hit->ready;
-  pthread_mutex_unlock(&g_tab_mu);
-  const hipError_t we = hipStreamWaitEvent(st, ev, 0);   // a no-op on the stream that built it
+  const hipError_t we = hipStreamWaitEvent(st, t->ready, 0);   // a no-op on the stream that built it
   if (we != hipSuccess) {
-    tab_release(hit);
+    tab_release(t);
     return fail(OZK_E_NO_DEVICE, "hipStreamWaitEvent failed: %s", hipGetErrorString(we));
   }
-  fp->aff = hit->aff;
-  fp->aff_phi = hit->aff_phi;
-  *out = hit;
+  fp->aff = t->aff;
+  fp->aff_phi = t->aff_phi;
+  *out = t;
   return OZK_OK;
 }
 
@@ -643,7 +632,10 @@ static int fb_table_host_base(int outerc, int ws, int n, const uint8_t* base_hos
                               hipStream_t st, FbPlan* fp, TabPin* pin) {
   constexpr size_t base_bytes = std::is_same<CV, G1Cfg>::value ? 96 : 192;
   *fp = fb_choose(outerc, ws, n);
-  if (fp->affine && env_int("OZK_FB_TABLE_CACHE", 1)) return tab_get<CV>(fp, outerc, ws, n, base_host, wsp, wsb, st, &pin->t);
+  if (fp->affine && env_int("OZK_FB_TABLE_CACHE", 1)) {
+    const int rc = tab_get<CV>(fp, outerc, ws, n, base_host, wsp, wsb, st, &pin->t);
+    if (rc || pin->t) return rc;   // (no cached table for this call: build one in the workspace, below)
+  }
   OZK_HIP(hipMemcpyAsync(d_base_scratch, base_host, base_bytes, hipMemcpyHostToDevice, st));
   OZK_HIP(hipStreamSynchronize(st));   // `base_host` is the caller's (pageable) memory
   return fb_build<CV>(*fp, outerc, ws, n, d_base_scratch, wsp, wsb, st);
@@ -817,6 +809,7 @@ int ozk_fixed_double_batch_msm_host(int32_t outerc1, int32_t ws1, int32_t outerc
 }
 
 int ozk_field_batch_mul_dev(const void* d_in, int32_t n, void* d_out, void* stream) {
+  hip_clear_stale();   // (ozk_common.h: a stale error of the calling thread is not this call's)
   if (!d_in || !d_out || n <= 0) return fail(OZK_E_INVALID, "bad argument");
   hipLaunchKernelGGL(k_field_mul, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const u32*)d_in, n,
                      (u32*)d_out);

@@ -1403,8 +1403,9 @@ __global__ void __launch_bounds__(64) k_finalize(const u32* __restrict__ A_w, co
 }
 
 // sum of k points given in wire-out format (affine or (0,1,0)); used for the multi-GPU reduce
+// (records `stride_words` apart: the sharded double MSM gathers G1 || G2 records of 576 bytes)
 template <class CV>
-__global__ void __launch_bounds__(64) k_points_sum(const u32* __restrict__ pts, int k, u32* __restrict__ out) {
+__global__ void __launch_bounds__(64) k_points_sum(const u32* __restrict__ pts, int k, int stride_words, u32* __restrict__ out) {
   using EA = typename CV::EA;
   using ET = ElemTraits<EA>;
   constexpr int OW = 2 * ET::WORDS;
@@ -1413,7 +1414,7 @@ __global__ void __launch_bounds__(64) k_points_sum(const u32* __restrict__ pts, 
   pts += opaque_zero();
   Jac<CV> r = jac_infinity<CV>();
   for (int i = 0; i < k; i++) {
-    const u32* p = pts + (size_t)i * 3 * OW;
+    const u32* p = pts + (size_t)i * stride_words;
     Jac<CV> q;
     q.X = ET::from_wire_out(p);
     q.Y = ET::from_wire_out(p + OW);

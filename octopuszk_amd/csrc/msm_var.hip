@@ -4,8 +4,12 @@
 // the two JNI natives of algebra.msm.VariableBaseMSM (.cu:1614-1788).
 #include "msm_var_driver.cuh"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
 #include <algorithm>
 #include <chrono>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -308,16 +312,35 @@ int ozk_var_msm_host(const uint8_t* bases, const uint8_t* scalars, int32_t n, in
 #endif
 }
 
-int ozk_var_double_msm_host(const uint8_t* bases_g1, const uint8_t* bases_g2, const uint8_t* scalars,
-                            int32_t n, int32_t task_id, uint8_t* out) {
+// d_result != nullptr (the sharded entry's RCCL form): the 576 bytes stay on the device, G1 (192) || G2 (384)
+static int var_double_msm_host_impl(const uint8_t* bases_g1, const uint8_t* bases_g2, const uint8_t* scalars,
+                                    int32_t n, int32_t task_id, uint8_t* out, uint8_t* d_result) {
   // G1 and G2 over the same scalars (VariableBaseMSM.cu:1772-1773); out = G1 (192) || G2 (384).
   // The reference runs them back to back, each with its own uploads.  Here the scalars go up once, and
   // the 192 n bytes of G2 bases are uploaded (the host thread staging pageable memory) while the G1 MSM
   // already runs on its own stream; the G1 tail then overlaps the G2 head.
-  if (!bases_g1 || !bases_g2 || !scalars || !out) return fail(OZK_E_INVALID, "null pointer argument");
+  if (!bases_g1 || !bases_g2 || !scalars || (!out && !d_result)) return fail(OZK_E_INVALID, "null pointer argument");
   if (n <= 0 || n > (1 << 24)) return fail(OZK_E_INVALID, "batch_size %d out of range [1, 2^24]", n);
   CtxGuard g;
   int rc = ctx_acquire(task_id, &g.c);
+  // both results out: to the host through the pinned result buffer, or device to device
+  auto finish = [&](HostCtx* c, uint8_t* d_out, hipStream_t s1, hipStream_t s2) -> int {
+    int r;
+    if (d_result) {
+      OZK_HIP(hipMemcpyAsync(d_result, d_out, 192, hipMemcpyDeviceToDevice, s1));
+      OZK_HIP(hipMemcpyAsync(d_result + 192, d_out + 256, 384, hipMemcpyDeviceToDevice, s2));
+    } else {
+      if ((r = small_d2h_begin(c, 0, d_out, 192, s1))) return r;
+      if ((r = small_d2h_begin(c, 1024, d_out + 256, 384, s2))) return r;
+    }
+    OZK_HIP(hipStreamSynchronize(s1));
+    OZK_HIP(hipStreamSynchronize(s2));
+    if (!d_result) {
+      small_d2h_end(c, 0, out, 192);
+      small_d2h_end(c, 1024, out + 192, 384);
+    }
+    return OZK_OK;
+  };
   if (rc) return rc;
   HostCtx* c = g.c;
   const int K = host_slices(n);
@@ -344,13 +367,7 @@ int ozk_var_double_msm_host(const uint8_t* bases_g1, const uint8_t* bases_g2, co
     if ((rc = host_sliced_msm<G2Cfg>(c, bases_g2, nullptr, n, K, per, d_b2, d_sc, d_w2, d_out + 256, c->slice_ev + K,
                                      c->st[1], up)))
       return rc;
-    if ((rc = small_d2h_begin(c, 0, d_out, 192, c->st[0]))) return rc;
-    if ((rc = small_d2h_begin(c, 1024, d_out + 256, 384, c->st[1]))) return rc;
-    OZK_HIP(hipStreamSynchronize(c->st[0]));
-    OZK_HIP(hipStreamSynchronize(c->st[1]));
-    small_d2h_end(c, 0, out, 192);
-    small_d2h_end(c, 1024, out + 192, 384);
-    return OZK_OK;
+    return finish(c, d_out, c->st[0], c->st[1]);
   }
   const size_t b1 = (size_t)n * 96, b2 = (size_t)n * 192, sc = (size_t)n * 32;
   const size_t w1 = var_msm_ws_bytes<G1Cfg>(n), w2 = var_msm_ws_bytes<G2Cfg>(n);
@@ -371,39 +388,185 @@ int ozk_var_double_msm_host(const uint8_t* bases_g1, const uint8_t* bases_g2, co
   OZK_HIP(hipStreamWaitEvent(s2, c->ev[0], 0));
   if ((rc = staged_h2d(c, d_b2, bases_g2, b2, s2))) return rc;
   if ((rc = var_msm_dev<G2Cfg>(d_b2, d_sc, n, d_out + 256, d_w2, w2, s2))) return rc;
-  if ((rc = small_d2h_begin(c, 0, d_out, 192, s1))) return rc;
-  if ((rc = small_d2h_begin(c, 1024, d_out + 256, 384, s2))) return rc;
-  OZK_HIP(hipStreamSynchronize(s1));
-  OZK_HIP(hipStreamSynchronize(s2));
-  small_d2h_end(c, 0, out, 192);
-  small_d2h_end(c, 1024, out + 192, 384);
-  return OZK_OK;
+  return finish(c, d_out, s1, s2);
+}
+int ozk_var_double_msm_host(const uint8_t* bases_g1, const uint8_t* bases_g2, const uint8_t* scalars,
+                            int32_t n, int32_t task_id, uint8_t* out) {
+  if (!out) return fail(OZK_E_INVALID, "null pointer argument");
+  return var_double_msm_host_impl(bases_g1, bases_g2, scalars, n, task_id, out, nullptr);
 }
 
 // In-process multi-GPU MSM for ONE caller (a serial Java prover calls the native once, with taskID 0: the
 // reference then uses one GPU, algebra_msm_VariableBaseMSM.cu:1249-1257; its multi-GPU form needs Spark
-// partitions, VariableBaseMSM.java:775-786).  The (scalar, base) index range is cut into `shards` contiguous
-// slices (shards <= 0: one per visible device); slice i runs the whole single-GPU pipeline on device
-// i % device_count from its own host thread and context; the 192 / 384-byte partials come back to the host
-// and are added on device 0 (the reduce(GroupT::add) of VariableBaseMSM.java:783) — the exchange is
-// shards x 192 B, so there is nothing for a collective library to do here (the one-process-per-GPU form,
-// octopuszk_amd/distributed.py, all-gathers the same partials over RCCL).
-static int var_msm_shard(const uint8_t* bases, const uint8_t* scalars, int n, int type, int task_id, uint8_t* out) {
-  return type == OZK_G1 ? var_msm_host<G1Cfg>(bases, scalars, n, task_id, out)
-                        : var_msm_host<G2Cfg>(bases, scalars, n, task_id, out);
+// partitions, VariableBaseMSM.java:775-786 / :805-818 for the double MSM).  The (scalar, base) index range is cut
+// into `shards` contiguous slices (shards <= 0: one per visible device); slice i runs the whole single-GPU pipeline
+// on device i % device_count from its own host thread and context.  Then the exchange north_star names — an
+// "all-reduce" of the partial accumulators, which for a group law RCCL does not know is an ALL-GATHER of the
+// affine partials plus a local point sum (the reduce(GroupT::add) of VariableBaseMSM.java:783):
+//   RCCL form (default when librccl loads and the communicators come up): every slice leaves its 192 / 384 / 576-byte
+//     partial in a send buffer on ITS device; one ncclAllGather per device (a group call over communicators made
+//     once per process by ncclCommInitAll) moves them over xGMI; k_points_sum runs on device 0 over the gathered
+//     records.  The partials never visit the host.
+//   host form (OZK_SHARD_RCCL=0, or RCCL unavailable / failing to initialise — e.g. a JVM host without librccl):
+//     partials back through the host, sum on device 0.  Round 2-3's only form.
+// Both give the same bytes (tests/test_sharded_gpu.py runs both on one device: ncclCommInitAll(ndev = 1)).  The
+// exchange is <= 64 x 576 B: latency-bound either way; nothing of it has been timed on more than one device.
+namespace {
+// ---- RCCL, bound at run time: libozk_hip.so must load in a JVM whose host has no librccl
+struct RcclApi {
+  void* lib = nullptr;
+  bool tried = false, ok = false;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+constexpr size_t SHARD_REC = 576;        // room for G1 (192) || G2 (384); single-curve calls use the first 192 / 384
+constexpr int SHARD_MAX = 64;
+struct ShardComm {   // the communicators over devices 0 .. D-1 and their buffers, made once per process and D
+  int D = 0;
+  std::vector<ncclComm_t> comm;
+  std::vector<hipStream_t> st;
+  std::vector<uint8_t*> d_send, d_recv;   // per device: SHARD_MAX records out, D * SHARD_MAX records in
+  uint8_t* d_sum = nullptr;               // device 0: 1 KiB for the summed point(s)
+  uint8_t* h_pin = nullptr;               // pinned host: infinity records in, result out
+};
+pthread_mutex_t g_shard_mu = PTHREAD_MUTEX_INITIALIZER;   // one sharded call at a time owns the communicators
+RcclApi g_rccl;
+std::vector<ShardComm*> g_shard_comms;
+thread_local int g_last_exchange = -1;
+
+bool rccl_load() {   // (g_shard_mu held)
+  if (g_rccl.tried) return g_rccl.ok;
+  g_rccl.tried = true;
+  for (const char* name : {"librccl.so.1", "librccl.so"}) {
+    g_rccl.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (g_rccl.lib) break;
+  }
+  if (!g_rccl.lib) return false;
+  auto sym = [&](const char* n) { return dlsym(g_rccl.lib, n); };
+  g_rccl.CommInitAll = (decltype(g_rccl.CommInitAll))sym("ncclCommInitAll");
+  g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy");
+  g_rccl.AllGather = (decltype(g_rccl.AllGather))sym("ncclAllGather");
+  g_rccl.GroupStart = (decltype(g_rccl.GroupStart))sym("ncclGroupStart");
+  g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))sym("ncclGroupEnd");
+  g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
+  g_rccl.ok = g_rccl.CommInitAll && g_rccl.CommDestroy && g_rccl.AllGather && g_rccl.GroupStart && g_rccl.GroupEnd &&
+              g_rccl.GetErrorString;
+  return g_rccl.ok;
+}
+void shard_comm_free(ShardComm* sc) {
+  for (int r = 0; r < (int)sc->comm.size(); r++)
+    if (sc->comm[r]) g_rccl.CommDestroy(sc->comm[r]);
+  for (int r = 0; r < sc->D; r++) {
+    if (hipSetDevice(r) != hipSuccess) continue;
+    if (r < (int)sc->st.size() && sc->st[r]) (void)hipStreamDestroy(sc->st[r]);
+    if (r < (int)sc->d_send.size() && sc->d_send[r]) (void)hipFree(sc->d_send[r]);
+    if (r < (int)sc->d_recv.size() && sc->d_recv[r]) (void)hipFree(sc->d_recv[r]);
+  }
+  if (sc->d_sum && hipSetDevice(0) == hipSuccess) (void)hipFree(sc->d_sum);
+  if (sc->h_pin) (void)hipHostFree(sc->h_pin);
+  delete sc;
+}
+// the communicator set over D devices, or nullptr (-> host form).  (g_shard_mu held)
+ShardComm* shard_comm_get(int D) {
+  for (ShardComm* sc : g_shard_comms)
+    if (sc->D == D) return sc;
+  if (!rccl_load()) return nullptr;
+  ShardComm* sc = new (std::nothrow) ShardComm();
+  if (!sc) return nullptr;
+  bool ok = true;
+  try {
+    sc->D = D;
+    sc->comm.assign(D, nullptr);
+    sc->st.assign(D, nullptr);
+    sc->d_send.assign(D, nullptr);
+    sc->d_recv.assign(D, nullptr);
+    std::vector<int> devs(D);
+    for (int r = 0; r < D; r++) devs[r] = r;
+    for (int r = 0; r < D && ok; r++) {
+      ok = hipSetDevice(r) == hipSuccess && hipStreamCreateWithFlags(&sc->st[r], hipStreamNonBlocking) == hipSuccess &&
+           hipMalloc((void**)&sc->d_send[r], SHARD_MAX * SHARD_REC) == hipSuccess &&
+           hipMalloc((void**)&sc->d_recv[r], (size_t)D * SHARD_MAX * SHARD_REC) == hipSuccess;
+    }
+    ok = ok && hipSetDevice(0) == hipSuccess && hipMalloc((void**)&sc->d_sum, 1024) == hipSuccess &&
+         hipHostMalloc((void**)&sc->h_pin, SHARD_MAX * SHARD_REC + 1024, hipHostMallocDefault) == hipSuccess;
+    if (ok) {
+      const ncclResult_t r = g_rccl.CommInitAll(sc->comm.data(), D, devs.data());
+      if (r != ncclSuccess) {
+        if (env_int("OZK_HOST_TRACE", 0)) fprintf(stderr, "[ozk] ncclCommInitAll(%d) failed: %s\n", D, g_rccl.GetErrorString(r));
+        ok = false;
+      }
+    }
+    if (ok) g_shard_comms.push_back(sc);
+  } catch (const std::exception&) {
+    ok = false;
+  }
+  if (!ok) {
+    shard_comm_free(sc);
+    return nullptr;
+  }
+  return sc;
+}
+// wire-out infinity (0, 1, 0) records for the slots no slice fills: kind 1 = G1, 2 = G2, 3 = G1 || G2
+void fill_infinity(uint8_t* rec, int kind) {
+  memset(rec, 0, SHARD_REC);
+  if (kind == 1) rec[64] = 1;
+  else if (kind == 2) rec[128] = 1;
+  else {
+    rec[64] = 1;
+    rec[192 + 128] = 1;
+  }
+}
+}  // namespace
+
+static int points_sum_strided(const void* d_points, int k, int type, size_t stride_bytes, void* d_out, hipStream_t st);
+
+// kind: 1 = G1 MSM, 2 = G2 MSM, 3 = double MSM (G1 || G2 over the same scalars)
+static int var_msm_shard(const uint8_t* b1, const uint8_t* b2, const uint8_t* scalars, int n, int kind, int task_id,
+                         uint8_t* out, uint8_t* d_result) {
+  if (kind == 1) return var_msm_host<G1Cfg>(b1, scalars, n, task_id, out, d_result);
+  if (kind == 2) return var_msm_host<G2Cfg>(b2, scalars, n, task_id, out, d_result);
+  return var_double_msm_host_impl(b1, b2, scalars, n, task_id, out, d_result);
 }
 
-int ozk_var_msm_sharded_host(const uint8_t* bases, const uint8_t* scalars, int32_t n, int32_t type, int32_t shards,
-                             uint8_t* out) {
-  if (!bases || !scalars || !out) return fail(OZK_E_INVALID, "null pointer argument");
+static int var_msm_sharded(const uint8_t* b1, const uint8_t* b2, const uint8_t* scalars, int32_t n, int kind, int32_t shards,
+                           uint8_t* out) {
   if (n <= 0) return fail(OZK_E_INVALID, "batch_size %d out of range", n);
   const int ndev = ozk_device_count();
   if (ndev <= 0) return fail(OZK_E_NO_DEVICE, "no HIP device available; this library has no CPU path");
   int k = shards > 0 ? shards : ndev;
   if (k > n) k = n;
-  if (k > 64) k = 64;
-  const size_t pt = type == OZK_G1 ? 96 : 192, ob = type == OZK_G1 ? 192 : 384;
-  if (k == 1) return var_msm_shard(bases, scalars, n, type, 0, out);
+  if (k > SHARD_MAX) k = SHARD_MAX;
+  const size_t ob = kind == 1 ? 192 : kind == 2 ? 384 : 576;
+  g_last_exchange = -1;
+  if (k == 1) return var_msm_shard(b1, b2, scalars, n, kind, 0, out, nullptr);
+  const int D = k < ndev ? k : ndev;             // devices in use: slice i on device i % ndev
+  const int slots = (k + D - 1) / D;             // slices per device
+  // the RCCL form needs the process's communicator set; a second sharded call that arrives while one is in flight
+  // takes the host form rather than wait (trylock)
+  ShardComm* sc = nullptr;
+  bool have_mu = false;
+  if (env_int("OZK_SHARD_RCCL", 1) && pthread_mutex_trylock(&g_shard_mu) == 0) {
+    have_mu = true;
+    sc = shard_comm_get(D);
+  }
+  struct Unlock {
+    bool on;
+    ~Unlock() {
+      if (on) pthread_mutex_unlock(&g_shard_mu);
+    }
+  } unlock{have_mu};
+  if (sc) {   // every slot an infinity record; the slices overwrite theirs
+    for (int j = 0; j < slots; j++) fill_infinity(sc->h_pin + (size_t)j * SHARD_REC, kind);
+    for (int r = 0; r < D; r++) {
+      OZK_HIP(hipSetDevice(r));
+      OZK_HIP(hipMemcpyAsync(sc->d_send[r], sc->h_pin, (size_t)slots * SHARD_REC, hipMemcpyHostToDevice, sc->st[r]));
+      OZK_HIP(hipStreamSynchronize(sc->st[r]));
+    }
+  }
   // (nothing may throw through the extern "C" boundary into a JVM: allocation and thread-start failures become codes)
   std::vector<uint8_t> partial;
   std::vector<int> rcs;
@@ -420,8 +583,10 @@ int ozk_var_msm_sharded_host(const uint8_t* bases, const uint8_t* scalars, int32
     for (int i = 0; i < k; i++) {
       const size_t lo = (size_t)i * base_n + (size_t)(i < rem ? i : rem);
       const int cnt = base_n + (i < rem ? 1 : 0);
-      th.emplace_back([&, i, lo, cnt] {
-        rcs[i] = var_msm_shard(bases + lo * pt, scalars + lo * 32, cnt, type, i, partial.data() + (size_t)i * ob);
+      uint8_t* d_res = sc ? sc->d_send[i % ndev] + (size_t)(i / ndev) * SHARD_REC : nullptr;
+      th.emplace_back([&, i, lo, cnt, d_res] {
+        rcs[i] = var_msm_shard(b1 ? b1 + lo * 96 : nullptr, b2 ? b2 + lo * 192 : nullptr, scalars + lo * 32, cnt, kind, i,
+                               partial.data() + (size_t)i * ob, d_res);
         if (rcs[i]) msgs[i] = err_buf();   // the message lives in that thread's buffer
       });
       started++;
@@ -434,22 +599,82 @@ int ozk_var_msm_sharded_host(const uint8_t* bases, const uint8_t* scalars, int32
   if (spawn_failed) return fail(OZK_E_NOMEM, "sharded MSM: could not start shard %d of %d (threads / host memory)", started, k);
   for (int i = 0; i < k; i++)
     if (rcs[i]) return fail(rcs[i], "shard %d of %d: %s", i, k, msgs[i].c_str());
-  // sum of the partials on device 0
+  if (sc) {
+    // all-gather of every device's `slots` records (one group call from this thread: the communicators of
+    // ncclCommInitAll), then the point sum on device 0
+    const size_t send = (size_t)slots * SHARD_REC;
+    ncclResult_t nr = g_rccl.GroupStart();
+    for (int r = 0; r < D && nr == ncclSuccess; r++)
+      nr = g_rccl.AllGather(sc->d_send[r], sc->d_recv[r], send, ncclUint8, sc->comm[r], sc->st[r]);
+    const ncclResult_t ne = g_rccl.GroupEnd();
+    if (nr == ncclSuccess) nr = ne;
+    if (nr != ncclSuccess) return fail(OZK_E_NO_DEVICE, "RCCL all-gather of the partial results failed: %s", g_rccl.GetErrorString(nr));
+    OZK_HIP(hipSetDevice(0));
+    for (int r = 1; r < D; r++) {   // (only device 0's copy is read; the other ranks' streams just drain)
+      OZK_HIP(hipSetDevice(r));
+      OZK_HIP(hipStreamSynchronize(sc->st[r]));
+    }
+    OZK_HIP(hipSetDevice(0));
+    int rc;
+    const int recs = D * slots;
+    if (kind == 3) {
+      if ((rc = points_sum_strided(sc->d_recv[0], recs, OZK_G1, SHARD_REC, sc->d_sum, sc->st[0]))) return rc;
+      if ((rc = points_sum_strided(sc->d_recv[0] + 192, recs, OZK_G2, SHARD_REC, sc->d_sum + 192, sc->st[0]))) return rc;
+    } else {
+      if ((rc = points_sum_strided(sc->d_recv[0], recs, kind == 1 ? OZK_G1 : OZK_G2, SHARD_REC, sc->d_sum, sc->st[0]))) return rc;
+    }
+    OZK_HIP(hipMemcpyAsync(sc->h_pin, sc->d_sum, ob, hipMemcpyDeviceToHost, sc->st[0]));
+    OZK_HIP(hipStreamSynchronize(sc->st[0]));
+    memcpy(out, sc->h_pin, ob);
+    g_last_exchange = 1;
+    return OZK_OK;
+  }
+  // host form: sum of the partials on device 0
   CtxGuard g;
   int rc = ctx_acquire(0, &g.c);
   if (rc) return rc;
   HostCtx* c = g.c;
-  if ((rc = ctx_reserve(c, pad256(partial.size()) + 1024))) return rc;
+  if ((rc = ctx_reserve(c, pad256(partial.size()) + 2048))) return rc;
   // (through the pinned result buffer both ways: host_ctx.h, small_d2h_begin)
   if (partial.size() + 1024 > RESULT_BYTES) return fail(OZK_E_INTERNAL, "partials do not fit the pinned result buffer");
   memcpy(c->result + 1024, partial.data(), partial.size());
   OZK_HIP(hipMemcpyAsync(c->arena, c->result + 1024, partial.size(), hipMemcpyHostToDevice, c->st[0]));
   uint8_t* d_out = c->arena + pad256(partial.size());
-  if ((rc = ozk_points_sum_dev(c->arena, k, type, d_out, c->st[0]))) return rc;
+  if (kind == 3) {
+    if ((rc = points_sum_strided(c->arena, k, OZK_G1, 576, d_out, c->st[0]))) return rc;
+    if ((rc = points_sum_strided(c->arena + 192, k, OZK_G2, 576, d_out + 192, c->st[0]))) return rc;
+  } else {
+    if ((rc = points_sum_strided(c->arena, k, kind == 1 ? OZK_G1 : OZK_G2, ob, d_out, c->st[0]))) return rc;
+  }
   if ((rc = small_d2h_begin(c, 0, d_out, ob, c->st[0]))) return rc;
   OZK_HIP(hipStreamSynchronize(c->st[0]));
   small_d2h_end(c, 0, out, ob);
+  g_last_exchange = 0;
   return OZK_OK;
+}
+
+int ozk_var_msm_sharded_host(const uint8_t* bases, const uint8_t* scalars, int32_t n, int32_t type, int32_t shards,
+                             uint8_t* out) {
+  if (!bases || !scalars || !out) return fail(OZK_E_INVALID, "null pointer argument");
+  if (type == OZK_G1) return var_msm_sharded(bases, nullptr, scalars, n, 1, shards, out);
+  return var_msm_sharded(nullptr, bases, scalars, n, 2, shards, out);
+}
+// the double MSM the same way (VariableBaseMSM.distributedDoubleMSM, VariableBaseMSM.java:805-818: per-partition
+// doubleMSM + reduce): out = 576 B, G1 (192) || G2 (384)
+int ozk_var_double_msm_sharded_host(const uint8_t* bases_g1, const uint8_t* bases_g2, const uint8_t* scalars, int32_t n,
+                                    int32_t shards, uint8_t* out) {
+  if (!bases_g1 || !bases_g2 || !scalars || !out) return fail(OZK_E_INVALID, "null pointer argument");
+  return var_msm_sharded(bases_g1, bases_g2, scalars, n, 3, shards, out);
+}
+// how the calling thread's last sharded call exchanged its partials: 1 = RCCL all-gather, 0 = through the host,
+// -1 = no exchange (one shard, or no sharded call yet)
+int ozk_shard_last_exchange(void) { return g_last_exchange; }
+// drops the process's RCCL communicators and their buffers (ozk_host_cache_release calls it)
+void ozk_shard_comms_release(void) {
+  pthread_mutex_lock(&g_shard_mu);
+  for (ShardComm* sc : g_shard_comms) shard_comm_free(sc);
+  g_shard_comms.clear();
+  pthread_mutex_unlock(&g_shard_mu);
 }
 
 // What the JNI native calls: ONE GPU, taskID % count, as the reference (algebra_msm_VariableBaseMSM.cu:1249-1257) —
@@ -464,15 +689,22 @@ int ozk_var_msm_auto_host(const uint8_t* bases, const uint8_t* scalars, int32_t 
     return ozk_var_msm_sharded_host(bases, scalars, n, type, env_int("OZK_SHARD_COUNT", 0), out);
   return ozk_var_msm_host(bases, scalars, n, type, task_id, out);
 }
+int ozk_var_double_msm_auto_host(const uint8_t* bases_g1, const uint8_t* bases_g2, const uint8_t* scalars, int32_t n,
+                                 int32_t task_id, uint8_t* out) {
+  if (env_int("OZK_SHARD", 0) && n >= env_int("OZK_SHARD_MIN_N", 1 << 21) && ozk_device_count() > 1)
+    return ozk_var_double_msm_sharded_host(bases_g1, bases_g2, scalars, n, env_int("OZK_SHARD_COUNT", 0), out);
+  return ozk_var_double_msm_host(bases_g1, bases_g2, scalars, n, task_id, out);
+}
 
-int ozk_points_sum_dev(const void* d_points, int32_t k, int32_t type, void* d_out, void* stream) {
-  if (!d_points || !d_out || k <= 0) return fail(OZK_E_INVALID, "bad argument");
+static int points_sum_strided(const void* d_points, int k, int type, size_t stride_bytes, void* d_out, hipStream_t st) {
+  hip_clear_stale();   // (ozk_common.h: a stale error of the calling thread is not this call's)
+  if (!d_points || !d_out || k <= 0 || (stride_bytes & 3)) return fail(OZK_E_INVALID, "bad argument");
   if (type == OZK_G1) {
-    hipLaunchKernelGGL((k_points_sum<G1Cfg>), dim3(1), dim3(64), 0, (hipStream_t)stream, (const u32*)d_points, k,
+    hipLaunchKernelGGL((k_points_sum<G1Cfg>), dim3(1), dim3(64), 0, st, (const u32*)d_points, k, (int)(stride_bytes / 4),
                        (u32*)d_out);
   } else {
 #if defined(OZK_WITH_G2)
-    hipLaunchKernelGGL((k_points_sum<G2Cfg>), dim3(1), dim3(64), 0, (hipStream_t)stream, (const u32*)d_points, k,
+    hipLaunchKernelGGL((k_points_sum<G2Cfg>), dim3(1), dim3(64), 0, st, (const u32*)d_points, k, (int)(stride_bytes / 4),
                        (u32*)d_out);
 #else
     return fail(OZK_E_INVALID, "G2 not built");
@@ -481,8 +713,12 @@ int ozk_points_sum_dev(const void* d_points, int32_t k, int32_t type, void* d_ou
   OZK_HIP(hipGetLastError());
   return OZK_OK;
 }
+int ozk_points_sum_dev(const void* d_points, int32_t k, int32_t type, void* d_out, void* stream) {
+  return points_sum_strided(d_points, k, type, type == OZK_G1 ? 192 : 384, d_out, (hipStream_t)stream);
+}
 
 int ozk_gen_bases_dev(uint64_t seed, int32_t n, int32_t type, void* d_out_wire, void* stream) {
+  hip_clear_stale();   // (ozk_common.h: a stale error of the calling thread is not this call's)
   if (!d_out_wire || n <= 0) return fail(OZK_E_INVALID, "bad argument");
   if (type != OZK_G1) return fail(OZK_E_INVALID, "only G1 synthetic bases are generated");
   // generator (1, 2) (BN254aG1Parameters.java:23-24), wire format
@@ -501,14 +737,25 @@ int ozk_gen_bases_dev(uint64_t seed, int32_t n, int32_t type, void* d_out_wire, 
   return OZK_OK;
 }
 
+// Enable / disable the timing of level-1 launches.  Single-device by construction: events and the clock buffer
+// belong to the device that is current here, and only launches on that device are recorded (ProfState::claim).
+// Serialised against concurrent launches by g_prof.mu; two threads enabling at once serialise too.
 int ozk_prof_enable(int on) {
+  struct Lock {
+    Lock() { pthread_mutex_lock(&g_prof.mu); }
+    ~Lock() { pthread_mutex_unlock(&g_prof.mu); }
+  } lock;
+  int dev = 0;
+  OZK_HIP(hipGetDevice(&dev));
   if (on == PROF_CLOCK) {
     constexpr int CAP = 1 << 16;  // launches per enable
-    int dev = 0;
-    OZK_HIP(hipGetDevice(&dev));
+    g_prof.mode = PROF_OFF;       // (nothing claims a slot while the buffer is replaced / cleared)
     if (g_prof.d_clk && g_prof.clk_device != dev) {
-      hipFree(g_prof.d_clk);
+      const int prev = g_prof.clk_device;
+      if (hipSetDevice(prev) == hipSuccess) (void)hipFree(g_prof.d_clk);   // a buffer is freed on its own device
+      OZK_HIP(hipSetDevice(dev));
       g_prof.d_clk = nullptr;
+      g_prof.clk_khz = 0.0;   // the calibration is per device
     }
     if (!g_prof.d_clk) {
       OZK_HIP(hipMalloc((void**)&g_prof.d_clk, (size_t)CAP * 2 * sizeof(unsigned long long)));
@@ -534,21 +781,31 @@ int ozk_prof_enable(int on) {
       g_prof.clk_khz = (double)(h[1] - h[0]) / ms;
     }
     OZK_HIP(hipMemset(g_prof.d_clk, 0, (size_t)CAP * 2 * sizeof(unsigned long long)));
-    g_prof.mode = g_prof.src = PROF_CLOCK;
+    g_prof.src = PROF_CLOCK;
     g_prof.count = 0;
+    g_prof.mode = PROF_CLOCK;
     return OZK_OK;
   }
-  if (on && !g_prof.created) {
-    hipEvent_t a, b;
-    g_prof.count = 0;
-    if (!g_prof.slot(&a, &b)) return fail(OZK_E_NOMEM, "cannot create profiling events");
-    g_prof.created = true;
-  }
   if (on) {
-    g_prof.mode = g_prof.src = PROF_EVENTS;
+    g_prof.mode = PROF_OFF;
+    if (g_prof.created && g_prof.ev_device != dev) {   // events are per device: a pool of another device is dropped
+      for (auto e : g_prof.e0) (void)hipEventDestroy(e);
+      for (auto e : g_prof.e1) (void)hipEventDestroy(e);
+      g_prof.e0.clear();
+      g_prof.e1.clear();
+      g_prof.created = false;
+    }
+    g_prof.count = 0;
+    if (!g_prof.created) {
+      hipEvent_t a, b;
+      if (!g_prof.slot(&a, &b)) return fail(OZK_E_NOMEM, "cannot create profiling events");
+      g_prof.created = true;
+      g_prof.ev_device = dev;
+    }
+    g_prof.src = PROF_EVENTS;
     g_prof.every = on >= 16 ? on - 16 + 1 : 1;  // on = 16 + k: time every (k + 1)-th launch only
     g_prof.seen = 0;
-    g_prof.count = 0;
+    g_prof.mode = PROF_EVENTS;
   } else {
     g_prof.mode = PROF_OFF;  // (the recorded launches stay readable until the next enable)
   }
@@ -560,7 +817,14 @@ int ozk_prof_dominant_kernel_stats(double* stats4, int* launches) {
   if (!stats4 || !launches) return fail(OZK_E_INVALID, "null pointer argument");
   std::vector<double> d;
   double tot = 0;
+  struct Lock {   // (no launch claims a slot while the records are read)
+    Lock() { pthread_mutex_lock(&g_prof.mu); }
+    ~Lock() { pthread_mutex_unlock(&g_prof.mu); }
+  } lock;
   if (g_prof.d_clk && g_prof.src == PROF_CLOCK) {
+    int dev = -1;
+    OZK_HIP(hipGetDevice(&dev));
+    if (dev != g_prof.clk_device) return fail(OZK_E_INVALID, "profiling was enabled on device %d, the caller is on device %d", g_prof.clk_device, dev);
     const double khz = g_prof.clk_khz;
     if (khz <= 0.0) return fail(OZK_E_INTERNAL, "device clock not calibrated");
     OZK_HIP(hipDeviceSynchronize());

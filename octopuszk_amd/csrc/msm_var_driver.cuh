@@ -6,6 +6,7 @@
 #include <pthread.h>
 #include <stdlib.h>
 
+#include <atomic>
 #include <vector>
 
 #ifndef OZK_WITH_G2
@@ -26,20 +27,33 @@ namespace ozk {
 //               launch timed, 660 with one in ten; separate hipEventRecord calls around the launch: 589), so
 //               bench.py uses it in a second pass as the cross-check, not inside the timed region.
 enum { PROF_OFF = 0, PROF_EVENTS = 1, PROF_CLOCK = 2 };
+// Process-wide, and since round 4 safe under concurrent callers: the launch counter, the event pool and the clock
+// buffer are claimed under `mu` (one uncontended lock per level-1 launch, only while profiling is on), and a launch
+// is timed only when it runs on the device the events / the clock buffer belong to — an MSM that task_id % count or
+// a shard routes to another device is simply not recorded (round 3 handed device A's buffer to a kernel on device
+// B: a memory fault waiting for its first multi-GPU run).
 struct ProfState {
-  int mode = PROF_OFF;
+  pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+  std::atomic<int> mode{PROF_OFF};
   int src = PROF_EVENTS;    // where the launches recorded since the last enable were timed
   int every = 1, seen = 0;  // PROF_EVENTS: time one launch in `every`
   int count = 0;
   std::vector<hipEvent_t> e0, e1;  // grown in blocks of 512 as launches are recorded (no cap)
   bool created = false;
+  int ev_device = -1;                   // PROF_EVENTS: the device the pool's events were created on
   unsigned long long* d_clk = nullptr;  // PROF_CLOCK: 2 words per launch, zeroed by ozk_prof_enable
   int clk_cap = 0, clk_device = -1;
   double clk_khz = 0.0;  // measured against the host's steady clock
-  // event pair for launch number `count`, or false when the pool cannot grow
+  // event pair for launch number `count`, or false when the pool cannot grow  (mu held)
   bool slot(hipEvent_t* a, hipEvent_t* b) {
     if ((size_t)count >= e0.size()) {
       const size_t want = e0.size() + 512;
+      try {
+        e0.reserve(want);
+        e1.reserve(want);
+      } catch (const std::exception&) {
+        return false;
+      }
       while (e0.size() < want) {
         hipEvent_t x = nullptr, y = nullptr;
         if (hipEventCreate(&x) != hipSuccess || hipEventCreate(&y) != hipSuccess) return false;
@@ -50,6 +64,24 @@ struct ProfState {
     *a = e0[count];
     *b = e1[count];
     return true;
+  }
+  // What the level-1 launch on the calling thread's current device carries: start / stop events (PROF_EVENTS) or
+  // two words of the clock buffer (PROF_CLOCK), or nothing.  Claims the launch's index.
+  void claim(hipEvent_t* a, hipEvent_t* b, unsigned long long** clk) {
+    *a = *b = nullptr;
+    *clk = nullptr;
+    if (mode.load(std::memory_order_relaxed) == PROF_OFF) return;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    pthread_mutex_lock(&mu);
+    const int m = mode.load(std::memory_order_relaxed);
+    if (m == PROF_EVENTS && created && dev == ev_device) {
+      if ((seen++ % every) == 0 && slot(a, b)) count++;
+      else *a = *b = nullptr;
+    } else if (m == PROF_CLOCK && d_clk && dev == clk_device && count < clk_cap) {
+      *clk = d_clk + 2 * (size_t)count++;
+    }
+    pthread_mutex_unlock(&mu);
   }
 };
 inline ProfState g_prof;
@@ -345,6 +377,7 @@ template <class CV>
 int var_msm_sort(const void* d_bases, const void* d_scalars, int n, void* sorted, size_t sorted_bytes,
                         void* sort_ws, size_t sort_ws_bytes, hipStream_t st, hipEvent_t order_ev = nullptr,
                         const void* prepared = nullptr) {
+  hip_clear_stale();   // (ozk_common.h: a stale error of the calling thread is not this call's)
   const MsmPlan p = plan_for<CV>(n);
   if (prepared && p.glv && !p.sd) return fail(OZK_E_INVALID, "prepared bases need the signed-digit plan");
   RegionBytes rb;
@@ -414,6 +447,7 @@ int var_msm_sort(const void* d_bases, const void* d_scalars, int n, void* sorted
 template <class CV>
 int var_msm_accum(int n, void* sorted, size_t sorted_bytes, void* accum_ws, size_t accum_ws_bytes, void* tail,
                          size_t tail_bytes, hipStream_t st, const void* prepared = nullptr) {
+  hip_clear_stale();   // (ozk_common.h: a stale error of the calling thread is not this call's)
   using CT = CV;  // (an out-of-line-multiplication variant for the tails measured 40 % slower)
   const MsmPlan p = plan_for<CV>(n);
   RegionBytes rb;
@@ -426,14 +460,14 @@ int var_msm_accum(int n, void* sorted, size_t sorted_bytes, void* accum_ws, size
   const int TB = 256;
   // level 1 over the sorted entries
   size_t lanes = (L.cap + p.L1 - 1) / p.L1;
+  // optional timing of this launch (ProfState::claim): events that ride on the kernel's own dispatch packet
+  // (hipExtLaunchKernelGGL start / stop events — separate hipEventRecord calls put two barrier packets around the
+  // launch, which cost the three-stage schedule 8 % of its throughput: 637 -> 589 Mscalar-mul/s,
+  // profiles/r03_schedule_experiments.txt), or two words the kernel's own waves stamp the device clock into
   hipEvent_t prof_e0 = nullptr, prof_e1 = nullptr;
-  // the events ride on the kernel's own dispatch packet (hipExtLaunchKernelGGL start / stop events): separate
-  // hipEventRecord calls put two barrier packets around the launch, which cost the three-stage schedule 8 % of its
-  // throughput (637 -> 589 Mscalar-mul/s, profiles/r03_schedule_experiments.txt)
-  const bool prof = g_prof.mode == PROF_EVENTS && g_prof.created && (g_prof.seen++ % g_prof.every) == 0 &&
-                    g_prof.slot(&prof_e0, &prof_e1);
   unsigned long long* clk = nullptr;
-  if (g_prof.mode == PROF_CLOCK && g_prof.d_clk && g_prof.count < g_prof.clk_cap) clk = g_prof.d_clk + 2 * (size_t)g_prof.count++;
+  g_prof.claim(&prof_e0, &prof_e1, &clk);
+  const bool prof = prof_e0 != nullptr;
   size_t acc_lds = CV::LDS_ACC ? (size_t)RunAccLds<CV>::LDS_WORDS * TB * sizeof(u32) : 0;  // 72 KiB for G2
   // G1: the kernel needs no LDS, but 4 blocks of 4 x 128 VGPRs fill a CU's register files completely, and a
   // kernel of another stream (a concurrent MSM's tail) dispatched later finds no wave slot until a block
@@ -462,7 +496,6 @@ int var_msm_accum(int n, void* sorted, size_t sorted_bytes, void* accum_ws, size
     rc_l1 = launch_l1(k_segreduce<CV, true, false>);
   }
   if (rc_l1) return rc_l1;
-  if (prof) g_prof.count++;
   // run merge: completes every bucket cut into at most RUN_MAX pieces; counts the surviving slots
   size_t n_in = 2 * lanes;
   hipLaunchKernelGGL((k_runmerge<CT>), dim3((unsigned)((lanes + TB - 1) / TB)), dim3(TB), 0, st, L.slot_bid[0],
@@ -514,6 +547,7 @@ int var_msm_head(const void* d_bases, const void* d_scalars, int n, void* ws, si
 template <class CV>
 int var_msm_tail(int n, void* tail, size_t tail_bytes, void* d_out, hipStream_t st,
                         hipEvent_t order_ev = nullptr, int mode = TAIL_LATENCY) {
+  hip_clear_stale();   // (ozk_common.h: a stale error of the calling thread is not this call's)
   using CT = CV;
   MsmPlan p = plan_for<CV>(n);
   MsmLayout L;
@@ -662,6 +696,7 @@ size_t host_sliced_ws_bytes(int K, int per) {
 template <class CV>
 int host_sliced_msm(HostCtx* c, const uint8_t* bases, const uint8_t* scalars, int n, int K, int per, uint8_t* d_bases,
                     uint8_t* d_sc, uint8_t* d_ws, uint8_t* d_out, hipEvent_t* ev, hipStream_t st, hipStream_t up) {
+  hip_clear_stale();   // (ozk_common.h: a stale error of the calling thread is not this call's)
   using IO = CurveIO<CV>;
   const size_t base_rec = (size_t)IO::WIRE_JAC_WORDS * 4;
   const size_t padded = (size_t)K * per;
@@ -700,8 +735,20 @@ int host_sliced_msm(HostCtx* c, const uint8_t* bases, const uint8_t* scalars, in
   return var_msm_tail<CV>(per, d_tails, tb, d_out, st);
 }
 
+// where a host entry point's result goes: the caller's host memory (through the context's pinned result buffer), or —
+// `d_result` != nullptr, the sharded entry's RCCL form — a device buffer on the same device (the partial then never
+// visits the host: it is all-gathered from there)
+inline int host_result(HostCtx* c, uint8_t* out, uint8_t* d_result, const uint8_t* d_out, size_t bytes, hipStream_t st) {
+  if (!d_result) return staged_d2h(c, out, d_out, bytes, st);
+  OZK_HIP(hipMemcpyAsync(d_result, d_out, bytes, hipMemcpyDeviceToDevice, st));
+  StatTimer tm(host_call_stats().sync_ms);
+  OZK_HIP(hipStreamSynchronize(st));
+  return OZK_OK;
+}
+
 template <class CV>
-int var_msm_host(const uint8_t* bases, const uint8_t* scalars, int n, int task_id, uint8_t* out) {
+int var_msm_host(const uint8_t* bases, const uint8_t* scalars, int n, int task_id, uint8_t* out,
+                 uint8_t* d_result = nullptr) {
   using IO = CurveIO<CV>;
   CtxGuard g;
   int rc = ctx_acquire(task_id, &g.c);
@@ -722,7 +769,7 @@ int var_msm_host(const uint8_t* bases, const uint8_t* scalars, int n, int task_i
     if ((rc = staged_h2d(c, d_sc, scalars, sc_bytes, st))) return rc;
     if ((rc = staged_h2d(c, d_bases, bases, base_bytes, st))) return rc;
     if ((rc = var_msm_dev<CV>(d_bases, d_sc, n, d_out, d_ws, ws_bytes, st))) return rc;
-    return staged_d2h(c, out, d_out, out_bytes, st);
+    return host_result(c, out, d_result, d_out, out_bytes, st);
   }
   const int per = host_slice_per(n, K);          // workspace and tails are laid out for `per` pairs
   const size_t padded = (size_t)K * per;
@@ -735,7 +782,7 @@ int var_msm_host(const uint8_t* bases, const uint8_t* scalars, int n, int task_i
   // uploads on the context's copy stream: they must not wait behind kernels
   if ((rc = host_sliced_msm<CV>(c, bases, scalars, n, K, per, d_bases, d_sc, d_ws, d_out, c->slice_ev, c->st[0], c->st[2])))
     return rc;
-  return staged_d2h(c, out, d_out, out_bytes, c->st[0]);
+  return host_result(c, out, d_result, d_out, out_bytes, c->st[0]);
 }
 
 // ---- prepared bases: the affine Montgomery records (GLV: both halves) of a base
@@ -748,6 +795,7 @@ size_t prepared_bytes(int n) {
 }
 template <class CV>
 int var_msm_prepare(const void* d_bases, int n, void* d_prepared, size_t bytes, hipStream_t st) {
+  hip_clear_stale();   // (ozk_common.h: a stale error of the calling thread is not this call's)
   const MsmPlan p = make_plan(n);
   if (p.glv && !p.sd) return fail(OZK_E_INVALID, "prepared bases need the signed-digit plan");
   if (bytes < prepared_bytes<CV>(n)) return fail(OZK_E_INVALID, "prepared buffer too small");
@@ -861,7 +909,7 @@ int bases_msm(BasesHandle* h, const uint8_t* scalars, uint8_t* out) {
   PREFIX template int ozk::var_msm_tail<ozk::G2Cfg>(int, void*, size_t, void*, hipStream_t, hipEvent_t, int);        \
   PREFIX template int ozk::var_msm_dev<ozk::G2Cfg>(const void*, const void*, int, void*, void*, size_t, hipStream_t,  \
                                                    const void*);                                                     \
-  PREFIX template int ozk::var_msm_host<ozk::G2Cfg>(const uint8_t*, const uint8_t*, int, int, uint8_t*);             \
+  PREFIX template int ozk::var_msm_host<ozk::G2Cfg>(const uint8_t*, const uint8_t*, int, int, uint8_t*, uint8_t*);             \
   PREFIX template size_t ozk::host_sliced_ws_bytes<ozk::G2Cfg>(int, int);                                            \
   PREFIX template int ozk::host_sliced_msm<ozk::G2Cfg>(ozk::HostCtx*, const uint8_t*, const uint8_t*, int, int, int, \
                                                        uint8_t*, uint8_t*, uint8_t*, uint8_t*, hipEvent_t*,         \

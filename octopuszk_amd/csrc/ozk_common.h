@@ -3,6 +3,8 @@
 // library-owned workspace.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <atomic>
 #include <pthread.h>
 #include <stdlib.h>
 #include <stdarg.h>
@@ -67,48 +69,56 @@ inline int ilog2(uint32_t v) {
   while (v >>= 1) r++;
   return r;
 }
-// Tuning switches (OZK_* environment variables) are read ONCE per process and cached: an MSM asks for
-// its plan several times (workspace-size query, head, tail), and a variable changing in between would
-// desynchronise the layouts.  ozk_tuning_reload() (tests, tuning scripts) drops the cache.
-struct EnvCache {
-  pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
-  int n = 0;
-  char names[64][40];
-  int vals[64];
-  bool has[64];
-};
-inline EnvCache& env_cache() {
-  static EnvCache c;
-  return c;
+// Tuning switches (OZK_* environment variables) are read ONCE and cached: an MSM asks for its plan several
+// times (workspace-size query, head, tail), and a variable changing in between would desynchronise the
+// layouts.  ozk_tuning_reload() (tests, tuning scripts) drops the cache.
+// The cache is PER THREAD (round 4): a host entry point reads dozens of knobs, and through round 3 every read
+// took one process-wide mutex — eight Spark task threads on eight devices serialised on it.  A thread's table
+// is valid for one generation of the process-wide counter that env_reload() bumps; a read costs a pointer
+// compare (the names are string literals) or a short strcmp, no lock and no shared write.
+inline std::atomic<unsigned>& env_generation() {
+  static std::atomic<unsigned> g(1);
+  return g;
 }
+struct EnvCache {
+  unsigned gen = 0;
+  int n = 0;
+  const char* ptr[96];
+  char names[96][40];
+  int vals[96];
+  bool has[96];
+};
 inline int env_int(const char* name, int dflt) {
-  EnvCache& c = env_cache();
-  pthread_mutex_lock(&c.mu);
+  static thread_local EnvCache c;
+  const unsigned g = env_generation().load(std::memory_order_acquire);
+  if (c.gen != g) {
+    c.gen = g;
+    c.n = 0;
+  }
   int k = 0;
   for (; k < c.n; k++)
-    if (strcmp(c.names[k], name) == 0) break;
-  if (k == c.n && c.n < 64 && strlen(name) < 40) {
+    if (c.ptr[k] == name || strcmp(c.names[k], name) == 0) break;
+  if (k == c.n) {
     const char* s = getenv(name);
-    strcpy(c.names[k], name);
-    c.has[k] = s && *s;
-    c.vals[k] = c.has[k] ? atoi(s) : 0;
-    c.n++;
+    const bool has = s && *s;
+    const int val = has ? atoi(s) : 0;
+    if (c.n < 96 && strlen(name) < 40) {
+      c.ptr[k] = name;
+      strcpy(c.names[k], name);
+      c.has[k] = has;
+      c.vals[k] = val;
+      c.n++;
+    }
+    return has ? val : dflt;
   }
-  int r = dflt;
-  if (k < c.n) {
-    if (c.has[k]) r = c.vals[k];
-  } else {  // table full: uncached
-    const char* s = getenv(name);
-    if (s && *s) r = atoi(s);
-  }
-  pthread_mutex_unlock(&c.mu);
-  return r;
+  return c.has[k] ? c.vals[k] : dflt;
 }
-inline void env_reload() {
-  EnvCache& c = env_cache();
-  pthread_mutex_lock(&c.mu);
-  c.n = 0;
-  pthread_mutex_unlock(&c.mu);
-}
+inline void env_reload() { env_generation().fetch_add(1, std::memory_order_acq_rel); }
+
+// The calling thread's HIP error state may hold an error left by somebody else's call (another native library in
+// the same process, torch's probes; the runtime keeps the last NON-success code until it is read —
+// hip_runtime_api.h, hipGetLastError).  Every function here that checks its kernel launches with
+// hipGetLastError() first drops whatever was there, so that the check reports this library's launches only.
+inline void hip_clear_stale() { (void)hipGetLastError(); }
 
 }  // namespace ozk

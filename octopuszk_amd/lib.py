@@ -22,6 +22,10 @@ _SIGS = {
     "ozk_var_double_msm_host": (ctypes.c_int, [vp, vp, vp, i32, i32, vp]),
     "ozk_var_msm_sharded_host": (ctypes.c_int, [vp, vp, i32, i32, i32, vp]),
     "ozk_var_msm_auto_host": (ctypes.c_int, [vp, vp, i32, i32, i32, vp]),
+    "ozk_var_double_msm_sharded_host": (ctypes.c_int, [vp, vp, vp, i32, i32, vp]),
+    "ozk_var_double_msm_auto_host": (ctypes.c_int, [vp, vp, vp, i32, i32, vp]),
+    "ozk_shard_last_exchange": (ctypes.c_int, []),
+    "ozk_shard_comms_release": (None, []),
     "ozk_var_msm_workspace_bytes": (sz, [i32, i32]),
     "ozk_var_msm_dev": (ctypes.c_int, [vp, vp, i32, i32, vp, vp, sz, vp]),
     "ozk_prof_enable": (ctypes.c_int, [ctypes.c_int]),
