@@ -329,6 +329,50 @@ def sorted_msm(C: Curve, scalars: Sequence[int], bases: Sequence):
     return result
 
 
+BOS_COSTER_MSM_THRESHOLD = 1048576  # VariableBaseMSM.java:29
+
+
+def bos_coster_msm(C: Curve, scalars: Sequence[int], bases: Sequence):
+    """VariableBaseMSM.java:86-119 (bosCosterMSM): a max-priority queue on the scalar; the two largest pairs
+    (e1, b1), (e2, b2) become (e1 - e2, b1) and (e2, b1 + b2) — e1 b1 + e2 b2 = (e1 - e2) b1 + e2 (b1 + b2) — unless
+    e1 div e2 >= 2^20, in which case e1 b1 is multiplied out (AbstractGroup.mul) and e2 goes back.  Scalars must be
+    positive: e2 = 0 divides by zero here as BigInteger.divide throws in the Java.  (java.util.PriorityQueue breaks
+    ties arbitrarily; the group element does not depend on it.)"""
+    import heapq
+    heap = []  # (-scalar, sequence number, scalar, base): heapq is a min-heap, the counter keeps bases uncompared
+    seq = 0
+    for sc, b in zip(scalars, bases):
+        heapq.heappush(heap, (-sc, seq, sc, b))
+        seq += 1
+
+    def poll():
+        return heapq.heappop(heap)[2:] if heap else None
+
+    result = C.zero
+    while True:
+        e1 = poll()
+        if e1 is None:
+            break
+        e2 = poll()
+        if e2 is None:
+            break
+        if e1[0] // e2[0] >= BOS_COSTER_MSM_THRESHOLD:  # :99-101
+            result = C.add(result, C.mul(e1[1], e1[0]))
+            heapq.heappush(heap, (-e2[0], seq, e2[0], e2[1]))
+            seq += 1
+        else:  # :102-110
+            value = e1[0] - e2[0]
+            if value != 0:
+                heapq.heappush(heap, (-value, seq, value, e1[1]))
+                seq += 1
+            heapq.heappush(heap, (-e2[0], seq, e2[0], C.add(e1[1], e2[1])))
+            seq += 1
+    while e1 is not None:  # :113-116
+        result = C.add(result, C.mul(e1[1], e1[0]))
+        e1 = poll()
+    return result
+
+
 def filtered_msm(C: Curve, scalars: Sequence[int], bases: Sequence):
     """VariableBaseMSM.java:736-770 (single-group restatement of the 0/1 filter
     in front of pippengerMSM)."""

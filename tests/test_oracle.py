@@ -203,16 +203,32 @@ def test_reference_toy_group_kat_literal():
     sc, bases = [3, 11, 2, 8], [5, 2, 7, 3]
     # SerialVariableBaseMSMTest.java:31-77 (Naive / Sorted / BosCoster expect 75),
     # DistributedVariableBaseMSMTest.java:92-109 (distributedMSM expects 75)
-    for f in (o.naive_msm, o.pippenger_msm, o.sorted_msm, o.filtered_msm):
+    for f in (o.naive_msm, o.pippenger_msm, o.sorted_msm, o.bos_coster_msm, o.filtered_msm):
         assert f(T, sc, bases) == 75, f.__name__
     # DistributedVariableBaseMSMTest.java:111-124: four x (3 * 5) = 60
-    for f in (o.naive_msm, o.pippenger_msm, o.sorted_msm, o.filtered_msm):
+    for f in (o.naive_msm, o.pippenger_msm, o.sorted_msm, o.bos_coster_msm, o.filtered_msm):
         assert f(T, [3] * 4, [5] * 4) == 60, f.__name__
     # a scalar as wide as BN254's: the windows of pippengerMSM cover 254 bits whatever the group
     big = [o.R - 1, 1 << 200, 12345678901234567890, 7]
     bs = [17, 9, 1 << 50, 143987564266532957]
     want = sum(s * b for s, b in zip(big, bs)) % T.MOD
     assert o.pippenger_msm(T, big, bs) == o.naive_msm(T, big, bs) == want
+    assert o.bos_coster_msm(T, big, bs) == want   # (R - 1) div 2^200 < 2^20 < 2^200 div 12345678901234567890: both branches
+
+
+def test_bos_coster_on_bn254_equals_naive_and_pippenger():
+    # VariableBaseMSM.bosCosterMSM (VariableBaseMSM.java:86-119) on the curve itself: positive scalars of mixed sizes,
+    # so that the subtract branch, the 2^20-ratio branch and the one-pair tail (:113-116) all run
+    import random
+    rnd = random.Random(7)
+    for G in (o.G1, o.G2):
+        pts = [G.to_affine(G.mul(G.one, rnd.randrange(1, 1 << 40))) for _ in range(9)]
+        sc = [rnd.randrange(1, o.R) for _ in range(5)] + [1, 3, rnd.randrange(1, 1 << 64), rnd.randrange(1, 1 << 200)]
+        want = G.to_affine(o.naive_msm(G, sc, pts))
+        assert G.to_affine(o.bos_coster_msm(G, sc, pts)) == want
+        assert G.to_affine(o.pippenger_msm(G, sc, pts)) == want
+    assert o.bos_coster_msm(o.G1, [], []) == o.G1.zero
+    assert o.G1.to_affine(o.bos_coster_msm(o.G1, [5], [o.G1.one])) == o.G1.to_affine(o.G1.mul(o.G1.one, 5))
 
 
 def test_reference_fft_kat_over_large_fp_literal():

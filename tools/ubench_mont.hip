@@ -8,6 +8,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <fenv.h>
+#include <vector>
+#include "fp64_mont.h"
 typedef uint32_t u32; typedef uint64_t u64;
 #define MASK 0x1fffffffu
 struct Fe { u32 l[9]; };
@@ -351,6 +354,76 @@ template<int V, int NCH> void run(const char* name, u64* out, int CU){
     printf("%-28s x%d waves/SIMD=%d %.3f ms  %.2f Gmul/s  ~%.0f cyc/wave-mul\n", name, NCH, w, ms, muls/ms*1e-6, cyc);
   }
 }
+
+// ---- round 4 ---------------------------------------------------------------------------------------------------
+// J: the FP64-FMA multiplication of tools/fp64_mont.h (52-bit limbs, hi / lo FMA pairs in round-toward-zero mode)
+template<int NCH>
+__global__ void __launch_bounds__(256) k_mont_fp64(u64* out, u32 a, u32 b, int iters){
+  asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 3");   // FP_ROUND of f64 / f16: toward zero
+  using namespace fp64mont;
+  Consts k;
+  for(int i=0;i<5;i++) k.p[i]=to_d(P52[i]);
+  k.pinv=to_d(PINV52);
+  Fe5 x[NCH], y;
+  for(int c=0;c<NCH;c++) for(int j=0;j<5;j++) x[c].d[j]=to_d(((u64)(threadIdx.x*2654435761u+j*40503u+a+c)<<17 ^ (u64)(j*77u+c)) & (j<4? M52 : ((1ull<<46)-1)));
+  for(int j=0;j<5;j++) y.d[j]=to_d(((u64)(threadIdx.x*40503u+j*2654435761u+b)<<19 ^ (u64)(j*13u)) & (j<4? M52 : ((1ull<<46)-1)));
+  for(int t=0;t<iters;t++){
+    #pragma unroll
+    for(int c=0;c<NCH;c++) x[c]=mul(x[c],y,k);
+  }
+  asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 0");
+  u64 s=0; for(int c=0;c<NCH;c++) for(int j=0;j<5;j++) s^=(u64)x[c].d[j] << (j*3);
+  out[blockIdx.x*blockDim.x+threadIdx.x]=s;
+}
+// the same chain on the host (fesetround) for the parity line
+static u64 fp64_host_lane(u32 tid, u32 a, u32 b, int iters){
+  using namespace fp64mont;
+  Consts k; for(int i=0;i<5;i++) k.p[i]=to_d(P52[i]); k.pinv=to_d(PINV52);
+  Fe5 x,y;
+  for(int j=0;j<5;j++) x.d[j]=to_d(((u64)(tid*2654435761u+j*40503u+a+0)<<17 ^ (u64)(j*77u+0)) & (j<4? M52 : ((1ull<<46)-1)));
+  for(int j=0;j<5;j++) y.d[j]=to_d(((u64)(tid*40503u+j*2654435761u+b)<<19 ^ (u64)(j*13u)) & (j<4? M52 : ((1ull<<46)-1)));
+  for(int t=0;t<iters;t++) x=mul(x,y,k);
+  u64 s=0; for(int j=0;j<5;j++) s^=(u64)x.d[j] << (j*3);
+  return s;
+}
+// EL: variant E with a loop body as long as the level-1 loop (ten multiplications over five values, straight-line,
+// ~2300 instructions = ~19 KB of code): does the instruction stream of a BIG loop issue as well as the 232-instruction
+// loop of E?  (Level 1 measures 5.4 cycles per instruction at 3 waves per SIMD, E 4.0.)
+__global__ void __launch_bounds__(256) k_mont_long(u64* out, u32 a, u32 b, int iters, unsigned long long* clk){
+  Fe v[5];
+  for(int c=0;c<5;c++) for(int j=0;j<9;j++) v[c].l[j]=(threadIdx.x*2654435761u+j*40503u+a+c*977u)&MASK;
+  const unsigned long long w0=wall_clock64(), c0=clock64();
+  for(int t=0;t<iters;t++){
+    v[0]=mul_E(v[0],v[1]); v[1]=mul_E(v[1],v[2]); v[2]=mul_E(v[2],v[3]); v[3]=mul_E(v[3],v[4]); v[4]=mul_E(v[4],v[0]);
+    v[0]=mul_E(v[0],v[2]); v[1]=mul_E(v[1],v[3]); v[2]=mul_E(v[2],v[4]); v[3]=mul_E(v[3],v[0]); v[4]=mul_E(v[4],v[1]);
+  }
+  const unsigned long long w1=wall_clock64(), c1=clock64();
+  if(clk && threadIdx.x==0){ clk[2*blockIdx.x]=w1-w0; clk[2*blockIdx.x+1]=c1-c0; }
+  u32 s=0; for(int c=0;c<5;c++) for(int j=0;j<9;j++) s^=v[c].l[j]; out[blockIdx.x*blockDim.x+threadIdx.x]=s;
+}
+// E with clock stamps: clock64() (s_memtime) against wall_clock64() (s_memrealtime, 100 MHz) over the kernel's loop
+template<int NCH>
+__global__ void __launch_bounds__(256) k_mont_clk(u64* out, u32 a, u32 b, int iters, unsigned long long* clk){
+  Fe x[NCH], y;
+  for(int c=0;c<NCH;c++) for(int j=0;j<9;j++) x[c].l[j]=(threadIdx.x*2654435761u+j*40503u+a+c)&MASK;
+  for(int j=0;j<9;j++) y.l[j]=(threadIdx.x*40503u+j*2654435761u+b)&MASK;
+  const unsigned long long w0=wall_clock64(), c0=clock64();
+  for(int t=0;t<iters;t++){
+    #pragma unroll
+    for(int c=0;c<NCH;c++) x[c]=mul_E(x[c],y);
+  }
+  const unsigned long long w1=wall_clock64(), c1=clock64();
+  if(clk && threadIdx.x==0){ clk[2*blockIdx.x]=w1-w0; clk[2*blockIdx.x+1]=c1-c0; }
+  u32 s=0; for(int c=0;c<NCH;c++) for(int j=0;j<9;j++) s^=x[c].l[j]; out[blockIdx.x*blockDim.x+threadIdx.x]=s;
+}
+static void report_clk(const char* what, unsigned long long* d_clk, int blocks){
+  std::vector<unsigned long long> h(2*(size_t)blocks);
+  hipMemcpy(h.data(), d_clk, h.size()*8, hipMemcpyDeviceToHost);
+  double rmin=1e30,rmax=0,rsum=0; int n=0;
+  for(int i=0;i<blocks;i++){ if(!h[2*i]) continue; double r=(double)h[2*i+1]/(double)h[2*i]; rmin=r<rmin?r:rmin; rmax=r>rmax?r:rmax; rsum+=r; n++; }
+  printf("    %s: clock64 ticks per wall_clock64 tick (100 MHz): mean %.3f min %.3f max %.3f over %d workgroups -> clock64 runs at %.1f MHz\n", what, rsum/n, rmin, rmax, n, rsum/n*100.0);
+}
+
 int main(){
   hipDeviceProp_t prop; hipGetDeviceProperties(&prop,0);
   int CU=prop.multiProcessorCount;
@@ -380,5 +453,43 @@ int main(){
   run<1,2>("B chained carry", o0, CU);
   run<2,2>("C chained + alignbit", o0, CU);
   run<3,2>("E per-column asm chains", o0, CU);
+
+  // ---- round 4
+  {
+    // parity of J: device == host (round toward zero on both) for every lane of one workgroup
+    fesetround(FE_TOWARDZERO);
+    hipLaunchKernelGGL((k_mont_fp64<1>), dim3(1), dim3(256), 0, 0, o0, 12345u, 678u, 7);
+    u64 hj[256]; hipMemcpy(hj, o0, sizeof(hj), hipMemcpyDeviceToHost);
+    int badj=0; for(u32 i=0;i<256;i++) if(hj[i]!=fp64_host_lane(i,12345u,678u,7)) badj++;
+    fesetround(FE_TONEAREST);
+    printf("variant J parity (device FP64-FMA chain == host chain, itself checked against exact integers by tools/fp64_mont_hostcheck.cc): %s\n", badj? "MISMATCH":"ok");
+    for(int nch : {1,2}) for(int w : {1,2,3,4,8}){
+      int blocks=CU*w, iters=256;
+      double ms = nch==1 ? timeit([&]{ hipLaunchKernelGGL((k_mont_fp64<1>), dim3(blocks), dim3(256), 0, 0, o0, 12345u, 678u, iters); })
+                         : timeit([&]{ hipLaunchKernelGGL((k_mont_fp64<2>), dim3(blocks), dim3(256), 0, 0, o0, 12345u, 678u, iters); });
+      double muls=(double)blocks*256*iters*nch; double cyc = ms*1e-3*2.4e9*(CU*4.0)/(muls/64.0);
+      printf("%-28s x%d waves/SIMD=%d %.3f ms  %.2f Gmul/s  ~%.0f cyc/wave-mul\n", "J FP64 FMA, 52-bit limbs", nch, w, ms, muls/ms*1e-6, cyc);
+    }
+    unsigned long long* d_clk; hipMalloc(&d_clk, sizeof(unsigned long long)*2*CU*16);
+    // E in a loop body of ten multiplications (code size of the level-1 loop), 3 waves per SIMD
+    for(int w : {1,2,3,4}){
+      int blocks=CU*w, iters=26;
+      hipMemset(d_clk,0,sizeof(unsigned long long)*2*blocks);
+      double ms=timeit([&]{ hipLaunchKernelGGL(k_mont_long, dim3(blocks), dim3(256), 0, 0, o0, 12345u, 678u, iters, d_clk); });
+      double muls=(double)blocks*256*iters*10; double cyc = ms*1e-3*2.4e9*(CU*4.0)/(muls/64.0);
+      printf("%-28s x1 waves/SIMD=%d %.3f ms  %.2f Gmul/s  ~%.0f cyc/wave-mul\n", "EL = E, 10 muls per loop body", w, ms, muls/ms*1e-6, cyc);
+      if(w==3) report_clk("EL", d_clk, blocks);
+    }
+    // E sustained: the same kernel for 0.3 ms, 1.2 ms (one level-1 launch), 5 ms and 40 ms — does the rate hold?
+    for(int iters : {256, 1024, 4096, 32768}){
+      int blocks=CU*3;
+      hipMemset(d_clk,0,sizeof(unsigned long long)*2*blocks);
+      double ms=timeit([&]{ hipLaunchKernelGGL((k_mont_clk<1>), dim3(blocks), dim3(256), 0, 0, o0, 12345u, 678u, iters, d_clk); });
+      double muls=(double)blocks*256*iters; double cyc = ms*1e-3*2.4e9*(CU*4.0)/(muls/64.0);
+      printf("%-28s x1 waves/SIMD=3 iters=%d %.3f ms  %.2f Gmul/s  ~%.0f cyc/wave-mul\n", "E sustained", iters, ms, muls/ms*1e-6, cyc);
+      report_clk("E sustained", d_clk, blocks);
+    }
+    hipFree(d_clk);
+  }
   return 0;
 }
