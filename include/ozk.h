@@ -210,6 +210,11 @@ int ozk_prof_dominant_kernel_ms(double* avg_ms, int* launches);
 /* stats4 = {mean, median, min, max} in ms (the box-to-box spread of the pool is ~10 %, so a single mean cannot
  * tell a 5 % gain from a slower box) */
 int ozk_prof_dominant_kernel_stats(double* stats4, int* launches);
+/* stats4 = {mean, median, min, max} over the launches recorded since ozk_prof_enable(2) of the SHADER clock in MHz
+ * each launch ran at (shader-clock / constant-rate ticks stamped inside the kernel): what makes kernel times of two
+ * boxes or two rounds comparable.  Profiling is single-device and serialised: launches on other devices than the one
+ * current at ozk_prof_enable are not recorded; concurrent callers are safe. */
+int ozk_prof_dominant_kernel_clock_mhz(double* stats4, int* launches);
 /* ticks per millisecond of the device clock, calibrated against the host's steady clock by the first
  * ozk_prof_enable(2) (MI355X: 100 011.8 kHz for a nominal 100 MHz); 0 before that */
 double ozk_prof_clock_khz(void);

@@ -173,6 +173,8 @@ void ctx_destroy(HostCtx* c) {
 }
 }  // namespace
 
+static __global__ void k_ctx_warm() {}
+
 HostCallStats& host_call_stats() {
   static thread_local HostCallStats s;
   return s;
@@ -206,6 +208,16 @@ int ctx_acquire(int task_id, HostCtx** out) {
       if (e == hipSuccess) e = hipEventCreateWithFlags(&c->stage_free[i], hipEventDisableTiming);
     }
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->result, RESULT_BYTES, hipHostMallocDefault);
+    // The runtime creates a stream's hardware queue at the stream's FIRST operation, not at hipStreamCreate: 7 ms
+    // inside whichever hipMemcpyAsync happened to be first on it (the "enqueue 7.09 ms" call of
+    // profiles/r03_host_path.txt: the double MSM is the only user of the second stream, so the cost surfaced in one
+    // of its calls, long after the context's own first call).  Paid here, once, where a context is created.
+    for (auto& s : c->st) {
+      if (e != hipSuccess) break;
+      hipLaunchKernelGGL(k_ctx_warm, dim3(1), dim3(1), 0, s);
+      e = hipGetLastError();
+      if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
     if (e != hipSuccess) {
       ctx_destroy(c);
       return fail(e == hipErrorOutOfMemory ? OZK_E_NOMEM : OZK_E_NO_DEVICE, "creating a host context failed: %s",

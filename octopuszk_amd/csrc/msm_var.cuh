@@ -1053,10 +1053,14 @@ segreduce_lane(const int t, const u32* __restrict__ bid_in, const u32* __restric
   bid_out[2 * (size_t)t + 1] = tail_bid;
 }
 
-// `clk` (level 1 only; may be null): two device-clock words of this launch, zero before it.  Every workgroup leaves
+// `clk` (level 1 only; may be null): four words of this launch, zero before it.  Every workgroup leaves
 // max(~start) in clk[0] and max(end) in clk[1] (wall_clock64: the constant-rate counter, hipDeviceAttributeWallClockRate),
 // so the launch's duration is clk[1] - ~clk[0] without any help from the runtime: HIP events around (or on) the
-// dispatch cost the three-stage schedule 4-13 % of its throughput, see ozk_prof_enable.
+// dispatch cost the three-stage schedule 4-13 % of its throughput, see ozk_prof_enable.  Round 4: clk[2] += the
+// SHADER clock ticks (clock64 = s_memtime: measured at 2.35-2.38 GHz under load against the 100 MHz of
+// wall_clock64, profiles/r04_ubench_mont.txt) and clk[3] += the constant-rate ticks that the first wave of every
+// workgroup spent in the kernel: clk[2] / clk[3] x the constant rate = the clock the chip actually ran this launch
+// at — what makes two boxes' (or two rounds') kernel times comparable (the sysfs sclk read after a run was noise).
 template <class CV, bool FIRST, bool LAZY = false>
 __global__ void __launch_bounds__(256, (FIRST && CV::LDS_ACC) ? 2 : 1)
 k_segreduce(const u32* __restrict__ bid_in, const u32* __restrict__ idx_in, const u32* __restrict__ pts_in,
@@ -1064,13 +1068,25 @@ k_segreduce(const u32* __restrict__ bid_in, const u32* __restrict__ idx_in, cons
             u32* __restrict__ buckets, u32* __restrict__ bid_out, u32* __restrict__ pts_out,
             int n_lanes, unsigned long long* __restrict__ clk) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long w0 = 0, c0 = 0;
   if constexpr (FIRST) {
-    if (clk != nullptr && threadIdx.x == 0) atomicMax(&clk[0], ~(unsigned long long)wall_clock64());
+    if (clk != nullptr && threadIdx.x == 0) {
+      w0 = (unsigned long long)wall_clock64();
+      c0 = (unsigned long long)clock64();
+      atomicMax(&clk[0], ~w0);
+    }
   }
   if (t < n_lanes)
     segreduce_lane<CV, FIRST, LAZY>(t, bid_in, idx_in, pts_in, d_count, n_in_static, L, buckets, bid_out, pts_out);
   if constexpr (FIRST) {
-    if (clk != nullptr && (threadIdx.x & 63) == 0) atomicMax(&clk[1], (unsigned long long)wall_clock64());  // (every wave: the last one to finish counts)
+    if (clk != nullptr && (threadIdx.x & 63) == 0) {
+      const unsigned long long w1 = (unsigned long long)wall_clock64();
+      atomicMax(&clk[1], w1);  // (every wave: the last one to finish counts)
+      if (threadIdx.x == 0) {
+        atomicAdd(&clk[2], (unsigned long long)clock64() - c0);
+        atomicAdd(&clk[3], w1 - w0);
+      }
+    }
   }
 }
 

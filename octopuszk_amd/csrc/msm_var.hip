@@ -758,7 +758,7 @@ int ozk_prof_enable(int on) {
       g_prof.clk_khz = 0.0;   // the calibration is per device
     }
     if (!g_prof.d_clk) {
-      OZK_HIP(hipMalloc((void**)&g_prof.d_clk, (size_t)CAP * 2 * sizeof(unsigned long long)));
+      OZK_HIP(hipMalloc((void**)&g_prof.d_clk, (size_t)CAP * 4 * sizeof(unsigned long long)));
       g_prof.clk_cap = CAP;
       g_prof.clk_device = dev;
     }
@@ -780,7 +780,7 @@ int ozk_prof_enable(int on) {
       if (ms <= 0.0 || h[1] <= h[0]) return fail(OZK_E_INTERNAL, "device clock calibration failed");
       g_prof.clk_khz = (double)(h[1] - h[0]) / ms;
     }
-    OZK_HIP(hipMemset(g_prof.d_clk, 0, (size_t)CAP * 2 * sizeof(unsigned long long)));
+    OZK_HIP(hipMemset(g_prof.d_clk, 0, (size_t)CAP * 4 * sizeof(unsigned long long)));
     g_prof.src = PROF_CLOCK;
     g_prof.count = 0;
     g_prof.mode = PROF_CLOCK;
@@ -828,12 +828,12 @@ int ozk_prof_dominant_kernel_stats(double* stats4, int* launches) {
     const double khz = g_prof.clk_khz;
     if (khz <= 0.0) return fail(OZK_E_INTERNAL, "device clock not calibrated");
     OZK_HIP(hipDeviceSynchronize());
-    std::vector<unsigned long long> h((size_t)g_prof.count * 2);
+    std::vector<unsigned long long> h((size_t)g_prof.count * 4);
     if (g_prof.count)
       OZK_HIP(hipMemcpy(h.data(), g_prof.d_clk, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     for (int i = 0; i < g_prof.count; i++) {
-      const unsigned long long t0 = ~h[2 * i], t1 = h[2 * i + 1];
-      if (h[2 * i] == 0 || t1 < t0) continue;  // launch never ran
+      const unsigned long long t0 = ~h[4 * i], t1 = h[4 * i + 1];
+      if (h[4 * i] == 0 || t1 < t0) continue;  // launch never ran
       const double ms = (double)(t1 - t0) / khz;
       d.push_back(ms);
       tot += ms;
@@ -864,6 +864,42 @@ int ozk_prof_dominant_kernel_ms(double* avg_ms, int* launches) {
   const int rc = ozk_prof_dominant_kernel_stats(st, launches);
   if (rc) return rc;
   *avg_ms = st[0];
+  return OZK_OK;
+}
+
+// stats[0..3] = mean, median, min, max over the launches recorded since ozk_prof_enable(2) of the SHADER clock (MHz)
+// each launch ran at: shader-clock ticks / constant-rate ticks spent inside the kernel by the first wave of every
+// workgroup (k_segreduce), times the calibrated constant rate
+int ozk_prof_dominant_kernel_clock_mhz(double* stats4, int* launches) {
+  if (!stats4 || !launches) return fail(OZK_E_INVALID, "null pointer argument");
+  struct Lock {
+    Lock() { pthread_mutex_lock(&g_prof.mu); }
+    ~Lock() { pthread_mutex_unlock(&g_prof.mu); }
+  } lock;
+  *launches = 0;
+  stats4[0] = stats4[1] = stats4[2] = stats4[3] = 0.0;
+  if (!g_prof.d_clk || g_prof.src != PROF_CLOCK || g_prof.clk_khz <= 0.0) return OZK_OK;
+  int dev = -1;
+  OZK_HIP(hipGetDevice(&dev));
+  if (dev != g_prof.clk_device) return fail(OZK_E_INVALID, "profiling was enabled on device %d, the caller is on device %d", g_prof.clk_device, dev);
+  OZK_HIP(hipDeviceSynchronize());
+  std::vector<unsigned long long> h((size_t)g_prof.count * 4);
+  if (g_prof.count) OZK_HIP(hipMemcpy(h.data(), g_prof.d_clk, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  std::vector<double> m;
+  double tot = 0;
+  for (int i = 0; i < g_prof.count; i++) {
+    if (h[4 * i + 3] == 0) continue;
+    const double mhz = (double)h[4 * i + 2] / (double)h[4 * i + 3] * g_prof.clk_khz * 1e-3;
+    m.push_back(mhz);
+    tot += mhz;
+  }
+  *launches = (int)m.size();
+  if (m.empty()) return OZK_OK;
+  std::sort(m.begin(), m.end());
+  stats4[0] = tot / (double)m.size();
+  stats4[1] = m[m.size() / 2];
+  stats4[2] = m.front();
+  stats4[3] = m.back();
   return OZK_OK;
 }
 

@@ -41,7 +41,7 @@ struct ProfState {
   std::vector<hipEvent_t> e0, e1;  // grown in blocks of 512 as launches are recorded (no cap)
   bool created = false;
   int ev_device = -1;                   // PROF_EVENTS: the device the pool's events were created on
-  unsigned long long* d_clk = nullptr;  // PROF_CLOCK: 2 words per launch, zeroed by ozk_prof_enable
+  unsigned long long* d_clk = nullptr;  // PROF_CLOCK: 4 words per launch (k_segreduce), zeroed by ozk_prof_enable
   int clk_cap = 0, clk_device = -1;
   double clk_khz = 0.0;  // measured against the host's steady clock
   // event pair for launch number `count`, or false when the pool cannot grow  (mu held)
@@ -79,7 +79,7 @@ struct ProfState {
       if ((seen++ % every) == 0 && slot(a, b)) count++;
       else *a = *b = nullptr;
     } else if (m == PROF_CLOCK && d_clk && dev == clk_device && count < clk_cap) {
-      *clk = d_clk + 2 * (size_t)count++;
+      *clk = d_clk + 4 * (size_t)count++;
     }
     pthread_mutex_unlock(&mu);
   }

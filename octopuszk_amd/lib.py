@@ -32,6 +32,7 @@ _SIGS = {
     "ozk_prof_dominant_kernel_ms": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
     "ozk_prof_dominant_kernel_stats": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
     "ozk_prof_clock_khz": (ctypes.c_double, []),
+    "ozk_prof_dominant_kernel_clock_mhz": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
     "ozk_var_msm_plan": (ctypes.c_int, [i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]),
     "ozk_var_msm_glv": (ctypes.c_int, [i32]),
     "ozk_gen_bases_dev": (ctypes.c_int, [ctypes.c_uint64, i32, i32, vp, vp]),

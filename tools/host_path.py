@@ -51,16 +51,31 @@ def fresh(a):
     return np.array(a, copy=True)
 
 
+ONLY = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--only=")]
+ALL_STATS = "--all-stats" in sys.argv
+
+
 def run(name, fn, make_inputs, reps, moved_mib, dev_ms=None):
-    times, stats = [], []
+    if ONLY and not any(o_ in name for o_ in ONLY):
+        return
+    import resource
+    times, stats, faults = [], [], []
     for _ in range(reps + 1):
         args = make_inputs()
+        ru0 = resource.getrusage(resource.RUSAGE_SELF)
         t0 = time.perf_counter()
         fn(*args)
         times.append((time.perf_counter() - t0) * 1e3)
+        ru1 = resource.getrusage(resource.RUSAGE_SELF)
+        faults.append((ru1.ru_minflt - ru0.ru_minflt, ru1.ru_nvcsw - ru0.ru_nvcsw, ru1.ru_nivcsw - ru0.ru_nivcsw))
         st = (ctypes.c_double * 10)()
         L.ozk_host_call_stats(st)
         stats.append(list(st))
+    if ALL_STATS:   # every call: wall, the library's own account of its waits, page faults / context switches of the process
+        f = ("acquire", "reserve", "stage_wait", "memcpy_in", "memcpy_out", "enqueue", "sync")
+        for i, (t, st_, fl) in enumerate(zip(times, stats, faults)):
+            print("    call %d: %6.2f ms (library %6.2f)  " % (i, t, st_[9]) + "  ".join("%s %.2f" % (n_, v) for n_, v in zip(f, st_))
+                  + "  | minor faults %d  ctx switches %d + %d" % fl, flush=True)
     warm = sorted(times[1:])
     extra = "" if dev_ms is None else "  | device-resident %.2f ms" % dev_ms
     print("%-46s first %8.2f ms | min %7.2f  median %7.2f ms | %5.0f MiB over PCIe%s   all: %s"
