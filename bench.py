@@ -85,6 +85,7 @@ def clock_stats(L):
     """shader clock (MHz) the level-1 launches recorded since the last ozk_prof_enable(2) ran at, stamped by the kernel
     itself: shader-clock ticks / constant-rate ticks inside the kernel (VERDICT r3 "next" 7: the sysfs value read after
     the run was noise — 94 / 106 / 540 / 1713 / 2400 MHz for the same workload)"""
+    from octopuszk_amd import lib as ozk
     c4, cl = (ctypes.c_double * 4)(), ctypes.c_int()
     ozk.check(L.ozk_prof_dominant_kernel_clock_mhz(c4, ctypes.byref(cl)))
     if cl.value == 0:
