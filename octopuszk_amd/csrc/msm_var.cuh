@@ -619,6 +619,72 @@ static __global__ void __launch_bounds__(SORT2_BLOCK, 8) k_sort2(const u32* __re
   }
 }
 
+// ------------------------------------------------------------------ the whole sort of a SMALL MSM in one launch
+// Up to 8192 sorted points (GLV: 4096 pairs) and 1024 buckets per window: one workgroup per window counts, ranks and
+// scatters its entries out of registers (LDS atomics), and reserves its piece of the sorted arrays with one global
+// atomic — the windows' pieces may land in any order: the accumulation only needs every bucket's entries adjacent.
+// Replaces k_sort1_count, the three scan kernels, k_sort1_scatter, k_sort2 and the four k_sortbig_* launches, which
+// for such an input are ten dependent dispatches of 1-6 us each with ~10 us between them: 2^10 pairs spent 130 of
+// their 940 us there (profiles/r04_small_n_probe.txt).  *total (zeroed by the caller) ends as the number of entries.
+constexpr int SORTS_BLOCK = 1024;
+constexpr int SORTS_PER = 8;
+constexpr int SORTS_MAX_N = SORTS_BLOCK * SORTS_PER;
+constexpr int SORTS_MAX_CB = 10;
+static __global__ void __launch_bounds__(SORTS_BLOCK) k_sort_small(const uint16_t* __restrict__ digits, int n, int cb, int sd,
+                                                                   u32* __restrict__ total, u32* __restrict__ hist,
+                                                                   u32* __restrict__ sidx, u32* __restrict__ sbid) {
+  __shared__ u32 cnt[1 << SORTS_MAX_CB];
+  __shared__ u32 off[1 << SORTS_MAX_CB];
+  __shared__ u32 wsum[SORTS_BLOCK / 64];
+  __shared__ u32 base_s;
+  const int w = blockIdx.x, t = threadIdx.x;
+  const int NB = 1 << cb;
+  if (t < NB) cnt[t] = 0;
+  block_sync();
+  u32 bk[SORTS_PER], rk[SORTS_PER];
+#pragma unroll
+  for (int k = 0; k < SORTS_PER; k++) {
+    const int i = k * SORTS_BLOCK + t;
+    const u32 code = (i < n) ? digits[(size_t)w * n + i] : 0u;
+    u32 b, neg;
+    const bool live = digit_decode(code, sd, b, neg);
+    rk[k] = live ? atomicAdd(&cnt[b], 1u) : 0u;
+    bk[k] = live ? (b | (neg << 31)) : BID_NONE;   // (b < 2^10: bit 31 is free for the sign; all ones = no entry)
+  }
+  block_sync();
+  const u32 c = (t < NB) ? cnt[t] : 0u;
+  u32 incl = c;
+  const int lane = t & 63;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const u32 x = __shfl_up(incl, o);
+    if (lane >= o) incl += x;
+  }
+  if (lane == 63) wsum[t >> 6] = incl;
+  block_sync();
+  u32 woff = 0, tot = 0;
+#pragma unroll
+  for (int q = 0; q < SORTS_BLOCK / 64; q++) {
+    if (q < (t >> 6)) woff += wsum[q];
+    tot += wsum[q];
+  }
+  if (t < NB) {
+    off[t] = woff + incl - c;
+    hist[((u32)w << cb) + (u32)t] = c;   // every bucket's count is written (no memset of hist)
+  }
+  if (t == 0) base_s = atomicAdd(total, tot);
+  block_sync();
+  const u32 base = base_s;
+#pragma unroll
+  for (int k = 0; k < SORTS_PER; k++) {
+    if (bk[k] == BID_NONE) continue;
+    const u32 b = bk[k] & 0x7fffffffu;
+    const u32 pos = base + off[b] + rk[k];
+    sidx[pos] = (u32)(k * SORTS_BLOCK + t) | (bk[k] & SIDX_NEG);
+    sbid[pos] = ((u32)w << cb) | b;
+  }
+}
+
 // ------------------------------------------------------------------ exclusive scan (3 kernels)
 constexpr int SCAN_ITEMS = 16;   // per lane
 constexpr int SCAN_BLOCK = 256;  // lanes -> 4096 items per block

@@ -140,7 +140,18 @@ static MsmPlan make_plan(int n) {
     long long l1 = per_bucket * 5 / 16;
     // at least 40 entries per lane; 56 from 2^20 points on (fewer pieces for the run merge: pipelined 2^20 G1 +1.5 %,
     // G2 2^20 -0.15 ms, a 2^20-constraint proof -0.3 ms; smaller MSMs lose 30-100 us with it)
-    const long long l1_min = env_int("OZK_MSM_L1_MIN", p.n >= (1 << 20) ? 56 : 40);
+    long long l1_min = env_int("OZK_MSM_L1_MIN", p.n >= (1 << 20) ? 56 : 40);
+    // SMALL MSMs (round 4): below ~2^17 pairs the launch does not fill the chip — 818 lanes at 2^10 — and the level is
+    // a chain of L1 dependent additions on lone waves (~5 us each): 200 us of a 0.94 ms MSM at n = 2^10
+    // (profiles/r04_small_n_probe.txt).  Shorter chunks as long as the lanes fit one wave per SIMD (65536 lanes), never
+    // below 8 entries (more pieces per bucket for the run merge; a bucket of a small MSM holds 16-32 entries):
+    // 2^10: 0.99 -> 0.84 ms, with the first window-sum level below 0.80.
+    {
+      const long long cap = (long long)p.n * p.W;
+      long long fit = cap / 65536;
+      if (fit < 8) fit = 8;
+      if (fit < l1_min) l1_min = fit;
+    }
     if (l1 < l1_min) l1 = l1_min;
     if (l1 > 1024) l1 = 1024;
     p.L1 = env_int("OZK_MSM_L1", (int)l1);
@@ -403,6 +414,14 @@ int var_msm_sort(const void* d_bases, const void* d_scalars, int n, void* sorted
                          (const uint8_t*)nullptr);
     hipLaunchKernelGGL(k_digits, dim3((n_in + TB - 1) / TB), dim3(TB), 0, st, scalars, n_in, p.c, p.W, L.digits);
   }
+  if (n <= SORTS_MAX_N && p.cb <= SORTS_MAX_CB && env_int("OZK_MSM_SMALL_SORT", 1)) {
+    // a small MSM: the whole sort in one launch (msm_var.cuh k_sort_small); L.total[0] was zeroed above
+    hipLaunchKernelGGL(k_sort_small, dim3(p.W), dim3(SORTS_BLOCK), 0, st, L.digits, n, p.cb, p.sd, L.total, L.hist, L.sidx,
+                       L.sbid);
+    if (order_ev && env_int("OZK_MSM_ORDER", 1)) OZK_HIP(hipStreamWaitEvent(st, order_ev, 0));
+    OZK_HIP(hipGetLastError());
+    return OZK_OK;
+  }
   // two-level counting sort by (window, digit): per-block LDS counts of the hi part, one global
   // exclusive scan, coarse scatter, then one block per coarse bin finishes by the lo part
   const size_t lds1 = (size_t)L.NH * sizeof(u32);
@@ -559,7 +578,9 @@ int var_msm_tail(int n, void* tail, size_t tail_bytes, void* d_out, hipStream_t 
     // the fused first level of a LONE tail: 8 buckets per lane for G1 (2^20: single MSM 2.63-2.71 -> 2.51-2.53 ms on
     // one box; 16: 2.60), the plan's 4 for G2 (8: 7.43 against 7.38 ms).  The buffers are sized for the plan's S,
     // which is never larger, so the fewer elements of a wider first level always fit.
-    const int s_lat = env_int("OZK_MSM_S_LAT", std::is_same<CV, G1Cfg>::value ? 8 : p.S);
+    // (small MSMs — fewer than 2^13 buckets per window — keep 4: the serial part of the level is what they wait for,
+    // 2^10: 0.84 -> 0.80 ms)
+    const int s_lat = env_int("OZK_MSM_S_LAT", (std::is_same<CV, G1Cfg>::value && p.cb >= 13) ? 8 : p.S);
     if (s_lat >= p.S && s_lat <= 64) p.S = 1 << ilog2((uint32_t)s_lat);
   }
   launch_wsum0<CV>(p, L, st, env_int("OZK_MSM_WSUM0_PRIO", 0), shape.fused);
