@@ -70,18 +70,43 @@ __global__ void __launch_bounds__(256) k_tw_full(const u32* __restrict__ small, 
   dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
 }
 
+// The twiddle PYRAMID (round 4): level s holds omega^(j 2^s), j < n / 2^(s+1), CONTIGUOUS, at entry n - (n >> s) of
+// the table (level 0 = the plain table omega^t, t < n / 2, at entry 0; n - 1 entries in all, twice the plain table).
+// A stage whose butterflies step through the plain table with stride 2^s reads level s instead: the last pass of a
+// 2^22 transform touched every 128-byte line of the 64 MiB table three times (strides 1, 2, 4: 64 MiB fetched each
+// for 64, 32 and 16 MiB of twiddles) and half of it once more — 246 of the pass's 630 MiB
+// (profiles/r03_pmc_hbm_fft_summary.csv); through the levels the same stages fetch 64 + 32 + 16 + 8 + 4 + 2 MiB.
+__global__ void __launch_bounds__(256) k_tw_pyramid(u32* __restrict__ tw, int n, int logn) {
+  const long long o = (long long)n / 2 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o > (long long)n - 2) return;
+  const unsigned r = (unsigned)((long long)n - o);            // 2 .. n / 2: distance to the end of the table
+  const int k = 32 - __clz(r - 1u);                           // ceil(log2 r): the level's size is 2^k / 2 ... entries
+  const int s = logn - k;
+  const long long base = (long long)n - ((long long)n >> s);
+  const long long j = o - base;
+  const uint4* src = reinterpret_cast<const uint4*>(tw + (size_t)(j << s) * 8);
+  uint4* dst = reinterpret_cast<uint4*>(tw + (size_t)o * 8);
+  dst[0] = src[0];
+  dst[1] = src[1];
+}
+
 // ---- one pass of K stages over an LDS tile ---------------------------------
 struct PassArgs {
   const u32* in;    // FIRST: wire input (n x 8 words, plain canonical); else packed workspace
   u32* out;         // LAST: wire out (n x out_stride words LE); else packed workspace (n x 8 words)
   int out_stride;   // 16: the JNI's 64-byte elements (upper half zero); 8: compact 32-byte elements
-  const u32* tw;    // omega^t, t < n/2, Montgomery, packed
+  const u32* tw;    // the twiddle pyramid (k_tw_pyramid): omega^t, t < n/2, then its stride-2^s subsamples; Montgomery, packed
   int n, logn;
   int sbits;        // stages already done = log2 of the butterfly distance entering this pass
   int K;            // stages in this pass
   const u32* scale; // LAST pass only, or null: out[i] is multiplied by scale[i] (n x 8 words, Montgomery form) on its
                     // way out — the coset / 1-over-m scalings of the witness map ride on the transform before them
 };
+
+// omega^(j 2^s): entry j of level s of the pyramid
+__device__ __forceinline__ const u32* tw_at(const PassArgs& a, u32 j, int s) {
+  return a.tw + ((size_t)a.n - ((size_t)a.n >> s) + (size_t)j) * 8;
+}
 
 template <int B, int TILE>
 __device__ __forceinline__ Fe<FrP, B> lds_load(const u32* lds, int e) {
@@ -127,8 +152,7 @@ __device__ __forceinline__ void fft_stage1(u32* lds, const PassArgs& a, int T, i
     const u32 mid0 = ((r >> (Q - 1)) << Q) | low;
     const u32 mid1 = mid0 | (1u << (Q - 1));
     const u32 j = (low << a.sbits) + tile_lo<FIRST>(a, blockIdx.x, T, ul);
-    const u32 ti = j << (a.logn - a.sbits - Q);
-    const auto w = ElemTraits<Fe<FrP, 16>>::load(a.tw + (size_t)ti * 8);
+    const auto w = ElemTraits<Fe<FrP, 16>>::load(tw_at(a, j, a.logn - a.sbits - Q));
     const u32 e0 = mid0 * T + ul, e1 = mid1 * T + ul;
     const auto x = lds_load<BIN, TILE>(lds, e0);
     const auto y = lds_load<BIN, TILE>(lds, e1);
@@ -225,10 +249,9 @@ __device__ __forceinline__ void fft_stage2(u32* lds, const PassArgs& a, int T, i
   const u32 m00 = ((r >> (Q - 1)) << (Q + 1)) | low;
   const u32 m01 = m00 | (1u << (Q - 1)), m10 = m00 | (1u << Q), m11 = m01 | (1u << Q);
   const u32 lo = tile_lo<FIRST>(a, blockIdx.x, T, ul);
-  const int sh1 = a.logn - a.sbits - Q;
-  const u32 t1 = ((low << a.sbits) + lo) << sh1;
-  const u32 t2a = ((low << a.sbits) + lo) << (sh1 - 1);
-  const u32 t2b = (((low | (1u << (Q - 1))) << a.sbits) + lo) << (sh1 - 1);
+  const int sh1 = a.logn - a.sbits - Q;   // stage Q steps through omega^t with stride 2^sh1, stage Q + 1 with half of it
+  const u32 j1 = (low << a.sbits) + lo;
+  const u32 j2b = ((low | (1u << (Q - 1))) << a.sbits) + lo;
   const u32 e00 = m00 * T + ul, e01 = m01 * T + ul, e10 = m10 * T + ul, e11 = m11 * T + ul;
   Fe<FrP, BIN> x00, x01, x10, x11;
   if constexpr (SRC_G) {
@@ -248,7 +271,7 @@ __device__ __forceinline__ void fft_stage2(u32* lds, const PassArgs& a, int T, i
     x10 = lds_load<BIN, TILE>(lds, e10);
     x11 = lds_load<BIN, TILE>(lds, e11);
   }
-  const auto w2b = TW::load(a.tw + (size_t)t2b * 8);
+  const auto w2b = TW::load(tw_at(a, j2b, sh1 - 1));
   Fe<FrP, 24> p, q, u;   // products / reduce_q results: < 19 p / 16
   Fe<FrP, BIN + 32> b1;
   if constexpr (FIRST && Q == 1) {
@@ -260,8 +283,8 @@ __device__ __forceinline__ void fft_stage2(u32* lds, const PassArgs& a, int T, i
     u = reduce_q(add(x10, q));
     b1 = sub_nc(x10, q);
   } else {
-    const auto w1 = TW::load(a.tw + (size_t)t1 * 8);
-    const auto w2a = TW::load(a.tw + (size_t)t2a * 8);
+    const auto w1 = TW::load(tw_at(a, j1, sh1));
+    const auto w2a = TW::load(tw_at(a, j1, sh1 - 1));
     p = mul(w1, x01);
     q = mul(w1, x11);
     const Fe<FrP, BIN + 32> b0 = add_nc(x10, q);
@@ -297,7 +320,7 @@ __device__ __forceinline__ void fft_stage1_from_global(u32* lds, const PassArgs&
 #pragma unroll
   for (int k = 0; k < 4; k++) gload<FIRST, TILE>(a, T, logT, m0 + k, ul, v0[k], v1[k]);
   const u32 lo = tile_lo<FIRST>(a, blockIdx.x, T, ul);
-  const auto w = ElemTraits<Fe<FrP, 16>>::load(a.tw + (size_t)(lo << (a.logn - a.sbits - 1)) * 8);
+  const auto w = ElemTraits<Fe<FrP, 16>>::load(tw_at(a, lo, a.logn - a.sbits - 1));
 #pragma unroll
   for (int k = 0; k < 4; k += 2) {
     const auto x = gunpack(v0[k], v1[k]), y = gunpack(v0[k + 1], v1[k + 1]);
@@ -456,7 +479,7 @@ static FftLayout fft_layout(int n, void* wsp, size_t wsb) {
   L.hi = (half + L.lo - 1) / L.lo;
   L.omega = b.take<u32>(8);
   L.small = b.take<u32>((size_t)(L.lo + L.hi) * 8);
-  L.tw = b.take<u32>((size_t)half * 8);
+  L.tw = b.take<u32>((size_t)(n > 1 ? n : 1) * 8);   // the pyramid: n - 1 entries
   L.buf[0] = b.take<u32>((size_t)n * 8);
   L.buf[1] = b.take<u32>((size_t)n * 8);
   b.take<u32>(64);
@@ -464,13 +487,19 @@ static FftLayout fft_layout(int n, void* wsp, size_t wsb) {
   return L;
 }
 
-// omega (device, wire form) -> tw[t] = omega^t, t < n/2 (scratch: small, (lo + hi) x 8 words)
+// omega (device, wire form) -> the twiddle pyramid: tw[t] = omega^t, t < n/2, and its subsampled levels behind it
+// (n entries of 8 words; scratch: small, (lo + hi) x 8 words)
 static void fft_build_twiddles(const u32* d_omega, int n, u32* small, u32* tw, hipStream_t st) {
   const int half = n / 2 > 0 ? n / 2 : 1;
   const int lo = half < TW_LO ? half : TW_LO;
   const int hi = (half + lo - 1) / lo;
   hipLaunchKernelGGL(k_tw_small, dim3((lo + hi + 255) / 256), dim3(256), 0, st, d_omega, lo, hi, small);
   hipLaunchKernelGGL(k_tw_full, dim3((half + 255) / 256), dim3(256), 0, st, small, lo, half, tw);
+  if (n >= 4) {
+    int logn = 0;
+    while ((1 << logn) < n) logn++;
+    hipLaunchKernelGGL(k_tw_pyramid, dim3((half + 255) / 256), dim3(256), 0, st, tw, n, logn);
+  }
 }
 
 // the transform proper: d_in (n x 8 words) -> d_out (n x out_stride words), in place allowed only
@@ -789,8 +818,8 @@ static QapLayout qap_layout(int m, void* wsp, size_t wsb) {
   const int hi = (m + TW_LO - 1) / TW_LO + 1;
   L.consts = b.take<QapConsts>(1);
   L.small = b.take<u32>((size_t)(TW_LO + hi) * 8);
-  L.tw_f = b.take<u32>((size_t)half * 8);
-  L.tw_i = b.take<u32>((size_t)half * 8);
+  L.tw_f = b.take<u32>((size_t)m * 8);   // twiddle pyramids: m - 1 entries each
+  L.tw_i = b.take<u32>((size_t)m * 8);
   L.pw_g = b.take<u32>((size_t)(TW_LO + hi) * 8);
   L.pw_gi = b.take<u32>((size_t)(TW_LO + hi) * 8);
   L.sc_g = b.take<u32>((size_t)m * 8);    // g^i / m and g^-i / m for every i (only used without the plan cache)
@@ -837,8 +866,8 @@ static int plan_get(int n, const uint8_t* omega, const uint8_t* g, hipStream_t s
     Bump b(base, ~(size_t)0);
     QapConsts* c = b.take<QapConsts>(1);
     u32* sm = b.take<u32>((size_t)(TW_LO + hi) * 8);
-    u32* twf = b.take<u32>((size_t)half * 8);
-    u32* twi = g ? b.take<u32>((size_t)half * 8) : nullptr;
+    u32* twf = b.take<u32>((size_t)(n > 1 ? n : 1) * 8);   // twiddle pyramids: n - 1 entries each
+    u32* twi = g ? b.take<u32>((size_t)n * 8) : nullptr;
     u32* pg = g ? b.take<u32>((size_t)(TW_LO + hi) * 8) : nullptr;
     u32* pgi = g ? b.take<u32>((size_t)(TW_LO + hi) * 8) : nullptr;
     u32* sg = g ? b.take<u32>((size_t)n * 8) : nullptr;

@@ -580,8 +580,18 @@ int var_msm_tail(int n, void* tail, size_t tail_bytes, void* d_out, hipStream_t 
     // which is never larger, so the fewer elements of a wider first level always fit.
     // (small MSMs — fewer than 2^13 buckets per window — keep 4: the serial part of the level is what they wait for,
     // 2^10: 0.84 -> 0.80 ms)
-    const int s_lat = env_int("OZK_MSM_S_LAT", (std::is_same<CV, G1Cfg>::value && p.cb >= 13) ? 8 : p.S);
-    if (s_lat >= p.S && s_lat <= 64) p.S = 1 << ilog2((uint32_t)s_lat);
+    // Small windows (round 4): the level is one wave per 64 S buckets, S serial buckets per lane (2 S dependent
+    // additions) and then log2-deep shuffles over the lanes that hold a segment — with 128 buckets per window (2^10
+    // pairs) and S = 8 only 16 lanes work, for 16 + 11 dependent additions; S = 2 fills the wave: 4 + 13.  So S =
+    // buckets / 64, at least 2.  (The fused level's output is 64 S times smaller than its input, so it fits the
+    // buffers — sized for the plan's S — for ANY S; the plain form needs S >= the plan's.)
+    int s_dflt = p.S;
+    if (std::is_same<CV, G1Cfg>::value) {
+      s_dflt = p.cb >= 13 ? 8 : (p.cb <= 7 ? 2 : (p.cb - 6 >= 3 ? 8 : (1 << (p.cb - 6))));
+      if (p.cb >= 10 && p.cb < 13) s_dflt = p.S;   // (2^13 .. 2^16 pairs: the plan's 4, as measured in round 3)
+    }
+    const int s_lat = env_int("OZK_MSM_S_LAT", s_dflt);
+    if (s_lat >= 2 && s_lat <= 64) p.S = 1 << ilog2((uint32_t)s_lat);
   }
   launch_wsum0<CV>(p, L, st, env_int("OZK_MSM_WSUM0_PRIO", 0), shape.fused);
   int m_in, g, k = 0;
