@@ -143,12 +143,19 @@ static MsmPlan make_plan(int n) {
     long long l1_min = env_int("OZK_MSM_L1_MIN", p.n >= (1 << 20) ? 56 : 40);
     // SMALL MSMs (round 4): below ~2^17 pairs the launch does not fill the chip — 818 lanes at 2^10 — and the level is
     // a chain of L1 dependent additions on lone waves (~5 us each): 200 us of a 0.94 ms MSM at n = 2^10
-    // (profiles/r04_small_n_probe.txt).  Shorter chunks as long as the lanes fit one wave per SIMD (65536 lanes), never
-    // below 8 entries (more pieces per bucket for the run merge; a bucket of a small MSM holds 16-32 entries):
-    // 2^10: 0.99 -> 0.84 ms, with the first window-sum level below 0.80.
-    {
+    // (profiles/r04_small_n_probe.txt).  Shorter chunks, down to 8 entries, as long as (a) the lanes still fit one
+    // wave per SIMD (65536 lanes) and (b) the buckets of the TOP window — whose digits have only top_bits significant
+    // bits, so that they hold 2^(c - top_bits) times the average — are cut into at most ~10 pieces: beyond RUN_MAX
+    // pieces the generic levels wake up (+0.2-0.3 ms: 2^12 pairs with 8-entry chunks took 1.19 ms against 0.88 with 16,
+    // same box, profiles/r04_small_n_ab.txt).  2^10: 0.97 -> 0.75 ms, 2^14: 1.06 -> 0.94, 2^15: 1.11 -> 0.97.
+    if (p.glv) {
       const long long cap = (long long)p.n * p.W;
       long long fit = cap / 65536;
+      const int top_bits = 127 - (p.W - 1) * p.c;
+      const int tb = top_bits - p.sd;
+      const long long per_top = (top_bits >= 1 && top_bits < p.c) ? ((long long)p.n >> (tb > 0 ? tb : 0)) : per_bucket;
+      const long long pieces = (per_top + 9) / 10;
+      if (fit < pieces) fit = pieces;
       if (fit < 8) fit = 8;
       if (fit < l1_min) l1_min = fit;
     }
@@ -580,16 +587,11 @@ int var_msm_tail(int n, void* tail, size_t tail_bytes, void* d_out, hipStream_t 
     // which is never larger, so the fewer elements of a wider first level always fit.
     // (small MSMs — fewer than 2^13 buckets per window — keep 4: the serial part of the level is what they wait for,
     // 2^10: 0.84 -> 0.80 ms)
-    // Small windows (round 4): the level is one wave per 64 S buckets, S serial buckets per lane (2 S dependent
-    // additions) and then log2-deep shuffles over the lanes that hold a segment — with 128 buckets per window (2^10
-    // pairs) and S = 8 only 16 lanes work, for 16 + 11 dependent additions; S = 2 fills the wave: 4 + 13.  So S =
-    // buckets / 64, at least 2.  (The fused level's output is 64 S times smaller than its input, so it fits the
-    // buffers — sized for the plan's S — for ANY S; the plain form needs S >= the plan's.)
+    // (The fused level's output is 64 S times smaller than its input, so it fits the buffers — sized for the plan's
+    // S — for ANY S; the plain form needs S >= the plan's.)
     int s_dflt = p.S;
-    if (std::is_same<CV, G1Cfg>::value) {
-      s_dflt = p.cb >= 13 ? 8 : (p.cb <= 7 ? 2 : (p.cb - 6 >= 3 ? 8 : (1 << (p.cb - 6))));
-      if (p.cb >= 10 && p.cb < 13) s_dflt = p.S;   // (2^13 .. 2^16 pairs: the plan's 4, as measured in round 3)
-    }
+    if (std::is_same<CV, G1Cfg>::value && p.cb >= 13) s_dflt = 8;   // (below 2^13 buckets per window the plan's 4 measures
+                                                                      // as well or better: profiles/r04_small_n_ab.txt)
     const int s_lat = env_int("OZK_MSM_S_LAT", s_dflt);
     if (s_lat >= 2 && s_lat <= 64) p.S = 1 << ilog2((uint32_t)s_lat);
   }
