@@ -99,12 +99,14 @@ struct PassArgs {
   int n, logn;
   int sbits;        // stages already done = log2 of the butterfly distance entering this pass
   int K;            // stages in this pass
+  int pyr;          // 1: twiddles from the pyramid's levels (default), 0: from level 0 with a stride
   const u32* scale; // LAST pass only, or null: out[i] is multiplied by scale[i] (n x 8 words, Montgomery form) on its
                     // way out — the coset / 1-over-m scalings of the witness map ride on the transform before them
 };
 
 // omega^(j 2^s): entry j of level s of the pyramid
 __device__ __forceinline__ const u32* tw_at(const PassArgs& a, u32 j, int s) {
+  if (!a.pyr) return a.tw + ((size_t)j << s) * 8;   // (OZK_FFT_TW_PYRAMID=0: the plain table with a stride, rounds 1-3)
   return a.tw + ((size_t)a.n - ((size_t)a.n >> s) + (size_t)j) * 8;
 }
 
@@ -570,6 +572,7 @@ static int fft_core(const u32* d_in, int n, const u32* tw, u32* d_out, int out_s
     a.logn = logn;
     a.sbits = sbits;
     a.K = K;
+    a.pyr = env_int("OZK_FFT_TW_PYRAMID", 1) != 0;
     a.scale = last ? scale : nullptr;
     const int tiles = n / tile;
     const int mode = !last ? 0 : (a.scale ? 2 : 1);
