@@ -17,9 +17,12 @@ MSMs round-robin on independent streams; see --help).  Prints ONE JSON line (ran
 max wall-time over ranks, inputs resident in HBM when the timed region starts.
 `roofline` is for the dominant kernel (level-1 bucket accumulation): algorithmic bytes
 (128 B per scalar-mul) / its duration inside the timed region, against the 8 TB/s HBM peak.  The
-duration comes from the device clock the kernel's own waves stamp (`kernel_ms`); the same steps are then repeated with
+duration comes from the device clock the kernel's own waves stamp (`kernel_ms`); the same K steps run once more with
 HIP start / stop events on every level-1 dispatch (`kernel_ms_hip_events`: an event-carrying dispatch slows the
-three-stage schedule, so it stays out of the timed region), and five lone MSMs give the kernel alone (`kernel_ms_alone`).
+three-stage schedule, so it stays out of the timed region — that pass runs FIRST, in front of the W warm-up steps, so
+that the timed steps see the clock the chip settles at under this load and not its ramp from idle), and five lone MSMs
+after the timed region give the kernel alone (`kernel_ms_alone`).  `roofline.shader_clock_mhz` is the shader clock the
+level-1 launches ran at, stamped by the kernel itself.
 `cpu_baseline` times the C oracle (oracle/ozk_oracle.c, a single-thread C port of the
 reference's serial Java pippengerMSM) on the SAME 2^20 inputs on one host core — rank 0,
 N = 1 only — and the bench asserts the GPU bytes equal the CPU bytes.
@@ -174,13 +177,22 @@ def main():
             raise SystemExit("--total-logn: 2^%d pairs do not divide over %d ranks" % (args.total_logn, world))
         n = (1 << args.total_logn) // world
     # inputs: rank r owns pairs [r*n, (r+1)*n) of the global MSM (distinct seeds per rank)
-    bases = dev.gen_g1_bases(n, seed=base_seed(rank))
+    # Order of the set-up (round 4): everything that leaves the device idle — the scalars (host), the allocations, the
+    # calibration of the device clock (two reads 25 ms apart, ozk_prof_enable) — comes FIRST, the generation of the
+    # synthetic bases (k_i G by 64-step double-and-add: ~70 ms of vector-ALU work) LAST, right in front of the warm-up.
+    # The chip raises its shader clock over tens of milliseconds of load: with the calibration's idle period in front
+    # of a 5-step (8 ms) warm-up, the 20 timed steps of the driver's command ran at 2.02-2.08 GHz against 2.24 GHz for
+    # the same schedule over 100 steps (roofline.shader_clock_mhz, profiles/r04_bench_*.json) — 10 % of clock that has
+    # nothing to do with the kernels.
     sc_host = rand_scalars(n, scalar_seed(rank))
     scalars = torch.from_numpy(sc_host).cuda()
     if args.schedule == "pipeline3" and args.in_flight >= 2:
         pipe = dev.VarMsmPipeline3(n, 1, depth=args.in_flight, tail_streams=args.tail_streams)
     else:
         pipe = dev.VarMsmPipeline(n, 1, depth=max(1, args.in_flight))
+    ozk.check(L.ozk_prof_enable(2))   # (calibrates and allocates; enabled again, cleared, in front of the timed steps)
+    ozk.check(L.ozk_prof_enable(0))
+    bases = dev.gen_g1_bases(n, seed=base_seed(rank))
     msm_bases = pipe.prepare(bases) if args.prepared else bases
     wb, wn = ctypes.c_int32(), ctypes.c_int32()
     ozk.check(L.ozk_var_msm_plan(n, ctypes.byref(wb), ctypes.byref(wn)))
@@ -248,15 +260,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # the first enable calibrates the device clock (two reads 25 ms apart) and allocates: before the warm-up, not
-    # between the warm-up and the timed steps, where it left the device idle for 25 ms (the 20 steps after that
-    # measured 1.71 ms each against 1.67 on the same box)
+    # The HIP-event cross-check pass (the contract's measurement of the dominant kernel: K steps of the same schedule
+    # with start / stop events on every level-1 dispatch, which slow the schedule and therefore stay out of the timed
+    # region) runs FIRST, then the W warm-up steps, then the K timed steps.  Round 4 moved it in front: the chip raises
+    # its shader clock over the first ~40 ms of this load — 2.03-2.08 GHz during 20 timed steps that follow a 5-step
+    # warm-up from idle, 2.20 after 25 steps, 2.24-2.26 after 60 (roofline.shader_clock_mhz; same box: 607-615 / 641 /
+    # 647-658 Mscalar-mul/s, profiles/r04_clock_ramp.txt) — and a run of 25 steps measured the ramp, not the kernels.
+    ev_stats, ev_launches, ev_ms_per_step, res_ev_bytes = None, 0, None, None
+    if not args.timed_only:
+        ozk.check(L.ozk_prof_enable(1))
+        run_steps(1)   # (first use of the event pool)
+        barrier()
+        ozk.check(L.ozk_prof_enable(1))
+        e0 = time.perf_counter()
+        res_ev = run_steps(args.steps)
+        barrier()
+        e1 = time.perf_counter()
+        es, el = (ctypes.c_double * 4)(), ctypes.c_int()
+        ozk.check(L.ozk_prof_dominant_kernel_stats(es, ctypes.byref(el)))
+        ozk.check(L.ozk_prof_enable(0))
+        ev_stats, ev_launches, ev_ms_per_step = [float(x) for x in es], el.value, (e1 - e0) / args.steps * 1e3
+        res_ev_bytes = bytes(res_ev.cpu().numpy())
+    # (the device clock was calibrated above, before the bases were generated: this enable only clears the records)
     ozk.check(L.ozk_prof_enable(2))
     res = run_steps(max(1, args.warmup))
     barrier()
-    # level-1 kernel duration per launch, from the device clock stamped by the kernel's own waves (ozk_prof_enable(2)):
-    # HIP events on the dispatch perturb the three-stage schedule (4-13 % of its throughput), so they are taken in a
-    # second, untimed pass below and reported next to this figure
+    # level-1 kernel duration per launch, from the device clock stamped by the kernel's own waves (ozk_prof_enable(2))
     ozk.check(L.ozk_prof_enable(2))
     t0 = time.perf_counter()
     res = run_steps(args.steps)
@@ -268,19 +297,8 @@ def main():
     ozk.check(L.ozk_prof_enable(0))
     avg_ms = ctypes.c_double(kstats[0])
     result_bytes = bytes(res.cpu().numpy())
-    ev_stats, ev_launches, ev_ms_per_step = None, 0, None
-    if not args.timed_only:
-        ozk.check(L.ozk_prof_enable(1))
-        e0 = time.perf_counter()
-        res_ev = run_steps(args.steps)
-        barrier()
-        e1 = time.perf_counter()
-        es, el = (ctypes.c_double * 4)(), ctypes.c_int()
-        ozk.check(L.ozk_prof_dominant_kernel_stats(es, ctypes.byref(el)))
-        ozk.check(L.ozk_prof_enable(0))
-        ev_stats, ev_launches, ev_ms_per_step = [float(x) for x in es], el.value, (e1 - e0) / args.steps * 1e3
-        if bytes(res_ev.cpu().numpy()) != result_bytes:
-            raise SystemExit("bench: the HIP-event pass returned a different point")
+    if res_ev_bytes is not None and res_ev_bytes != result_bytes:
+        raise SystemExit("bench: the HIP-event pass returned a different point")
     # latency of ONE MSM with nothing else in flight (not part of `value`), and the level-1 kernel's duration in that
     # situation: inside the timed schedule the kernel shares the vector ALU with the next MSM's sort and the previous
     # MSMs' tails, so its duration there says how the chip was shared, its duration alone what the kernel costs
@@ -365,7 +383,7 @@ def main():
                         "mean": round(ev_stats[0], 4), "median": round(ev_stats[1], 4), "min": round(ev_stats[2], 4),
                         "max": round(ev_stats[3], 4), "launches": ev_launches,
                         "ms_per_step_of_that_pass": round(ev_ms_per_step, 4),
-                        "source": "HIP start/stop events on the dispatch, second pass of the same steps (an event-carrying "
+                        "source": "HIP start/stop events on the dispatch, a separate pass of the same steps in front of the warm-up (an event-carrying "
                                   "dispatch slows the three-stage schedule, hence not inside the timed region)"},
                     "kernel_ms_alone": alone,
                     "shader_clock_mhz": {"in_schedule": clock_timed, "alone": clock_alone,

@@ -5,6 +5,7 @@
 //   B  + the gather: index word -> 64-byte record, requested one entry ahead, decoded when consumed; indices
 //        random over a 128 MiB table
 //   C  B with sequential indices (cache-friendly)
+//   G  B with the prefetched record in LDS instead of registers (gfx950 LDS-direct 16-byte loads)
 //   D  B + the run logic (bucket id per entry, run boundaries every ~64 entries, finished runs stored as 160-byte records)
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DOZK_WITH_G2 tools/ubench_l1loop.hip -o tools/ubench_l1loop
 #include <hip/hip_runtime.h>
@@ -29,6 +30,25 @@ __global__ void __launch_bounds__(256) k_loop(const u32* __restrict__ idx, const
   u32 v_cur = idx_c[0];
   u32 v_next = idx_c[1];
   typename Acc::Raw r = Acc::load_raw(pts, v_cur);
+  // MODE 6: the prefetched record goes straight into LDS (global_load_lds_dwordx4: gfx950's 16-byte LDS-direct load,
+  // no VGPRs in between) — two 4 KiB buffers per wave, lane l's q-th 16 bytes at [q][l] — and is read back with
+  // ds_read_b128 when the entry is consumed
+  u32* wbuf = dummy + (threadIdx.x >> 6) * 2048;
+  const u32 lane = threadIdx.x & 63;
+  auto lds_issue = [&](u32 v, u32 b) {
+    const u32* rec = pts + (size_t)(v & ~SIDX_NEG) * 16;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rec + 4 * q),
+                                       (__attribute__((address_space(3))) void*)(wbuf + b * 1024 + q * 256), 16, 0, 0);
+  };
+  auto lds_take = [&](u32 b) {
+    typename Acc::Raw x;
+#pragma unroll
+    for (int q = 0; q < 4; q++) x.w[q] = *reinterpret_cast<const uint4*>(wbuf + b * 1024 + q * 256 + lane * 4);
+    return x;
+  };
+  if constexpr (MODE == 6) lds_issue(v_cur, 0);
   u32 b_cur = bid_c[0];
   u32 cur = BID_NONE;
   Aff<EA> qfix = Acc::decode_unsigned(r);
@@ -51,7 +71,8 @@ __global__ void __launch_bounds__(256) k_loop(const u32* __restrict__ idx, const
     if constexpr (MODE == 4) sink ^= r.w[0].x ^ r.w[1].y ^ r.w[2].z ^ r.w[3].w;
     const u32 k1 = (k + 1 < n_e) ? k + 1 : n_e - 1;
     const u32 k2 = (k + 2 < n_e) ? k + 2 : n_e - 1;
-    if constexpr (MODE != 0 && MODE != 5) r = Acc::load_raw(pts, v_next);
+    if constexpr (MODE == 6) lds_issue(v_next, (k + 1u) & 1u);
+    else if constexpr (MODE != 0 && MODE != 5) r = Acc::load_raw(pts, v_next);
     if constexpr (MODE == 3) b_cur = bid_c[k1];
     v_cur = v_next;
     if constexpr (MODE != 0 && MODE != 5) v_next = idx_c[k2];
@@ -118,15 +139,17 @@ int main() {
     (void)hipMemcpy(d_pts, h_pts.data(), NP * 64, hipMemcpyHostToDevice);
   }
   const size_t lds = 41216;
-  const char* names[6] = {"A formula, q in registers (same q: +-q cancels, INVALID)", "B + gather (random, one entry ahead)", "C + gather (sequential indices)",
+  const char* names[7] = {"A formula, q in registers (same q: +-q cancels, INVALID)", "B + gather (random, one entry ahead)", "C + gather (sequential indices)",
                           "D + run logic and run-end stores (random gather)", "E gather issued, record unused; formula on a register q",
-                          "F no loads, q changed by register ops every entry"};
-  for (int mode = 0; mode < 6; mode++) {
+                          "F no loads, q changed by register ops every entry",
+                          "G = B with the record prefetched into LDS (global_load_lds_dwordx4)"};
+  for (int mode = 0; mode < 7; mode++) {
     double ms = mode == 0   ? timeit([&] { hipLaunchKernelGGL(k_loop<0>, dim3(blocks), dim3(256), lds, 0, d_idx, d_bid, d_pts, d_buckets, d_out, L); })
                 : mode == 1 ? timeit([&] { hipLaunchKernelGGL(k_loop<1>, dim3(blocks), dim3(256), lds, 0, d_idx, d_bid, d_pts, d_buckets, d_out, L); })
                 : mode == 2 ? timeit([&] { hipLaunchKernelGGL(k_loop<1>, dim3(blocks), dim3(256), lds, 0, d_seq, d_bid, d_pts, d_buckets, d_out, L); })
                 : mode == 4 ? timeit([&] { hipLaunchKernelGGL(k_loop<4>, dim3(blocks), dim3(256), lds, 0, d_idx, d_bid, d_pts, d_buckets, d_out, L); })
                 : mode == 5 ? timeit([&] { hipLaunchKernelGGL(k_loop<5>, dim3(blocks), dim3(256), lds, 0, d_idx, d_bid, d_pts, d_buckets, d_out, L); })
+                : mode == 6 ? timeit([&] { hipLaunchKernelGGL(k_loop<6>, dim3(blocks), dim3(256), lds, 0, d_idx, d_bid, d_pts, d_buckets, d_out, L); })
                             : timeit([&] { hipLaunchKernelGGL(k_loop<3>, dim3(blocks), dim3(256), lds, 0, d_idx, d_bid, d_pts, d_buckets, d_out, L); });
     const double adds = (double)NE;
     printf("%-52s %.3f ms for %.2f M additions -> %.3f ms per 16.78 M\n", names[mode], ms, adds * 1e-6, ms * 16.777216e6 / adds);
