@@ -179,3 +179,36 @@ def test_qap_instance_on_device_equals_host_and_oracle(shape):
     w = z.root_of_unity(host.degree)
     ind = z.r1cs_to_qap_relation_dev(r1cs, pow(w, 5, o.R))
     assert not isinstance(ind, z.QAPRelationDevice) and ind.Zt == 0
+
+
+def test_lagrange_entry_refuses_a_t_inside_the_domain():
+    """ozk_qap_lagrange_dev with t = omega^k: one denominator t - omega^i is zero and the shared inversion of its lane
+    would silently zero eight coefficients.  The entry point computes t^m on the host and returns
+    OZK_E_INVALID; the reference takes its indicator branch there (FFTAuxiliary.java:262-276), as zksnark.py does on
+    its side.  A t outside the domain still works through the same call."""
+    import ctypes
+    import torch
+    from octopuszk_amd import lib
+    from oracle import bn254 as o
+    L = lib.load()
+    m = 1 << 10
+    omega = o.fr_root_of_unity(m)
+    wsb = int(L.ozk_qap_lagrange_workspace_bytes(m))
+    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    out = torch.empty(m * 32, dtype=torch.uint8, device="cuda")
+    zt = torch.empty(32, dtype=torch.uint8, device="cuda")
+    st = int(torch.cuda.current_stream().cuda_stream)
+    le = lambda v: ctypes.create_string_buffer(int(v).to_bytes(32, "little"), 32)
+    for k in (0, 1, 7, m - 1):
+        rc = L.ozk_qap_lagrange_dev(ctypes.cast(le(pow(omega, k, o.R)), ctypes.c_void_p), ctypes.cast(le(omega), ctypes.c_void_p), m,
+                                    int(out.data_ptr()), int(zt.data_ptr()), int(ws.data_ptr()), wsb, st)
+        assert rc != 0 and b"domain" in L.ozk_last_error(), k
+    t = 123456789
+    lib.check(L.ozk_qap_lagrange_dev(ctypes.cast(le(t), ctypes.c_void_p), ctypes.cast(le(omega), ctypes.c_void_p), m,
+                                     int(out.data_ptr()), int(zt.data_ptr()), int(ws.data_ptr()), wsb, st))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().reshape(m, 32)
+    want = g.lagrange_coefficients(t, m)   # FFTAuxiliary.serialRadix2LagrangeCoefficients restated (oracle/groth16.py)
+    zt_v = int.from_bytes(bytes(zt.cpu().numpy()), "little")
+    assert zt_v == (pow(t, m, o.R) - 1) % o.R
+    assert [int.from_bytes(bytes(r), "little") for r in got] == [w % o.R for w in want]
