@@ -492,7 +492,7 @@ ShardComm* shard_comm_get(int D) {
            hipMalloc((void**)&sc->d_recv[r], (size_t)D * SHARD_MAX * SHARD_REC) == hipSuccess;
     }
     ok = ok && hipSetDevice(0) == hipSuccess && hipMalloc((void**)&sc->d_sum, 1024) == hipSuccess &&
-         hipHostMalloc((void**)&sc->h_pin, SHARD_MAX * SHARD_REC + 1024, hipHostMallocDefault) == hipSuccess;
+         hipHostMalloc((void**)&sc->h_pin, SHARD_MAX * SHARD_REC + 1024, hipHostMallocPortable) == hipSuccess;   // (read by every device)
     if (ok) {
       const ncclResult_t r = g_rccl.CommInitAll(sc->comm.data(), D, devs.data());
       if (r != ncclSuccess) {
