@@ -244,8 +244,11 @@ def main():
         if args.schedule == "streams":
             return run_steps_streams(k)
         res, prev = None, None
-        for _ in range(k):
-            t = pipe.submit(msm_bases, scalars, prepared=args.prepared)
+        three = isinstance(pipe, dev.VarMsmPipeline3) and os.environ.get("OZK_BENCH_LAST_LATENCY", "1") != "0"
+        for i in range(k):
+            # (the last MSM of a burst of k: nothing follows it, so its tail takes the latency shape — VarMsmPipeline3)
+            t = (pipe.submit(msm_bases, scalars, prepared=args.prepared, last=(i == k - 1)) if three
+                 else pipe.submit(msm_bases, scalars, prepared=args.prepared))
             if pipe.depth == 1:
                 res = finish(t)
                 continue

@@ -174,7 +174,10 @@ class VarMsmPipeline3:
         _lib.check(L.ozk_var_msm_prepare_dev(_ptr(d_bases), self.n, self.type, _ptr(out), nbytes, _stream()))
         return out
 
-    def submit(self, d_bases, d_scalars, prepared=False):
+    def submit(self, d_bases, d_scalars, prepared=False, last=False):
+        """last=True: the caller knows that no MSM follows this one (the end of a burst, a prover's final MSM): its
+        tail then runs with the chip to itself and takes the LATENCY shape of the window sums (fused first level +
+        wave levels: ~40 dependent additions shorter) instead of the throughput shape the overlapped tails use."""
         L = _lib.load()
         k = self.count
         s, slot = k % 2, k % self.depth
@@ -201,8 +204,12 @@ class VarMsmPipeline3:
         self.accum_done[s].record(self.acc)
         T = self.tail_st[k % len(self.tail_st)]
         T.wait_event(self.accum_done[s])
-        _lib.check(L.ozk_var_msm_tail_dev(self.n, self.type, _ptr(self.tails[slot]), self.tail_bytes,
-                                          _ptr(self.outs[slot]), int(T.cuda_stream)))
+        if last:
+            _lib.check(L.ozk_var_msm_tail_mode_dev(self.n, self.type, _ptr(self.tails[slot]), self.tail_bytes,
+                                                   _ptr(self.outs[slot]), int(T.cuda_stream), None, 0))
+        else:
+            _lib.check(L.ozk_var_msm_tail_dev(self.n, self.type, _ptr(self.tails[slot]), self.tail_bytes,
+                                              _ptr(self.outs[slot]), int(T.cuda_stream)))
         self.tail_done[slot].record(T)
         self.count += 1
         return k
