@@ -46,3 +46,28 @@ def gpu_var_msm(ws, d_bases, d_scalars, group=None) -> torch.Tensor:
     HIP point sum.  `ws` is a device.VarMsmWorkspace for the local slice size."""
     from . import device as dev
     return distributed_var_msm(lambda: ws.run(d_bases, d_scalars), dev.points_sum, ws.type, group)
+
+
+def distributed_var_double_msm(local_partial_fn, sum_fn, group=None, always_collective=False) -> torch.Tensor:
+    """VariableBaseMSM.distributedDoubleMSM (VariableBaseMSM.java:805-818: per-partition doubleMSM, then reduce(add) of
+    the G1 and of the G2 component): local_partial_fn() -> this rank's 576-byte partial, G1 (192) || G2 (384) as
+    ozk_var_double_msm_host lays them out; ONE all-gather of the 576-byte records, then the two point sums."""
+    partial = local_partial_fn()
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not always_collective):
+        return partial
+    world = dist.get_world_size(group)
+    rec = all_gather_partials(partial, group).view(world, 576)
+    g1 = sum_fn(rec[:, :192].contiguous().view(-1), world, 1)
+    g2 = sum_fn(rec[:, 192:].contiguous().view(-1), world, 2)
+    return torch.cat([g1.view(-1), g2.view(-1)])
+
+
+def gpu_var_double_msm(ws_g1, ws_g2, d_bases_g1, d_bases_g2, d_scalars, group=None) -> torch.Tensor:
+    """The production composition of the double MSM on one rank: the two HIP MSMs over the local slice (the same
+    scalars), one RCCL all-gather of the 576-byte partial, two HIP point sums."""
+    from . import device as dev
+
+    def local():
+        return torch.cat([ws_g1.run(d_bases_g1, d_scalars).view(-1), ws_g2.run(d_bases_g2, d_scalars).view(-1)])
+
+    return distributed_var_double_msm(local, dev.points_sum, group)

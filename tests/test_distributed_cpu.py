@@ -76,3 +76,57 @@ def test_two_rank_sharded_msm_matches_single():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert got[0] == want and got[1] == want
+
+
+def _worker_double(rank, world, port, n, pts1, pts2, scalars, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from octopuszk_amd import distributed as D
+    lo, hi = D.shard_range(n, rank, world)
+    sc, p1, p2 = scalars[lo:hi], pts1[lo:hi], pts2[lo:hi]
+
+    def local_partial():   # what ozk_var_double_msm_host returns for the slice: G1 (192) || G2 (384)
+        raw = (o.g1_out_le(o.G1.to_affine(o.pippenger_msm(o.G1, sc, p1))) +
+               o.g2_out_le(o.G2.to_affine(o.pippenger_msm(o.G2, sc, p2))))
+        return torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+
+    def sum_fn(gathered, k, type_):
+        G, size = (o.G1, 192) if type_ == 1 else (o.G2, 384)
+        dec = o.g1_from_out_le if type_ == 1 else o.g2_from_out_le
+        enc = o.g1_out_le if type_ == 1 else o.g2_out_le
+        g = bytes(gathered.numpy())
+        acc = G.zero
+        for i in range(k):
+            acc = G.add(acc, dec(g[size * i:size * (i + 1)]))
+        return torch.frombuffer(bytearray(enc(G.to_affine(acc))), dtype=torch.uint8)
+
+    out = D.distributed_var_double_msm(local_partial, sum_fn)
+    q.put((rank, bytes(out.numpy())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_double_msm_over_gloo_matches_single(world):
+    """VariableBaseMSM.distributedDoubleMSM (VariableBaseMSM.java:805-818) as octopuszk_amd.distributed composes it:
+    per-rank double MSM over an index-range slice, ONE all-gather of the 576-byte G1 || G2 partials, two point sums."""
+    rng = random.Random(11)
+    n = 23
+    p1 = [o.G1.to_affine(o.G1.mul(o.G1.one, rng.randrange(1, 1 << 40))) for _ in range(n)]
+    p2 = [o.G2.to_affine(o.G2.mul(o.G2.one, rng.randrange(1, 1 << 40))) for _ in range(n)]
+    p1[2], p2[5] = o.G1.zero, o.G2.zero
+    scalars = [rng.randrange(o.R) for _ in range(n)]
+    want = (o.g1_out_le(o.G1.to_affine(o.naive_msm(o.G1, scalars, p1))) +
+            o.g2_out_le(o.G2.to_affine(o.naive_msm(o.G2, scalars, p2))))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_double, args=(r, world, port, n, p1, p2, scalars, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(got[r] == want for r in range(world))
