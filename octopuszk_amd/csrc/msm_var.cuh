@@ -92,7 +92,10 @@ OZK_HD void signed_digit_codes(const u32 (&e)[8], int c, int W, bool neg, Emit e
 }
 
 // Packed coarse word: index << 8 | lo8, lo8 = low bucket bits (8 unsigned / 7 signed) | neg << 7 (signed).
-// In the sorted index array the sign travels in bit 31.
+// The sorted ENTRIES are 8-byte pairs (base index, bucket id), the sign of the digit in bit 31 of the index (round 4:
+// one array of pairs instead of an index array and a bucket-id array — every lane of the level-1 kernel walks its own
+// chunk, so each of its streams costs one scattered VMEM instruction per entry: one 8-byte load instead of two 4-byte
+// ones measured 3-4 % on the loop, profiles/r04_ubench_l1loop.txt variant I).
 constexpr u32 SIDX_NEG = 0x80000000u;
 
 #if defined(__HIPCC__)
@@ -460,8 +463,7 @@ static __global__ void __launch_bounds__(256) k_sortbig_scan(const BigBins* __re
 static __global__ void __launch_bounds__(SORT_BLOCK) k_sortbig_scatter(const u32* __restrict__ coarse,
                                                                 const BigBins* __restrict__ bb,
                                                                 const u32* __restrict__ T, int c, int lo_bits,
-                                                                u32 sign_bit, int NH, u32* __restrict__ sidx,
-                                                                u32* __restrict__ sbid) {
+                                                                u32 sign_bit, int NH, uint2* __restrict__ sent) {
   __shared__ u32 cur[256];
   const u32 lo_mask = (1u << lo_bits) - 1u;
   const u32 n_items = bb->n_items;
@@ -482,8 +484,7 @@ static __global__ void __launch_bounds__(SORT_BLOCK) k_sortbig_scatter(const u32
       const u32 lo = v & lo_mask;
       const u32 pos = lds_rank<OZK_SORTBIG_AGG>(cur, lo, live);
       if (live) {
-        sidx[pos] = (v >> 8) | ((v & sign_bit) << 24);
-        sbid[pos] = bucket0 + lo;
+        sent[pos] = make_uint2((v >> 8) | ((v & sign_bit) << 24), bucket0 + lo);
       }
     }
     block_sync();
@@ -508,8 +509,7 @@ constexpr u32 S2_TILE = S2_PER * SORT2_BLOCK;  // 8704: a coarse bin of 2^21 poi
 static __global__ void __launch_bounds__(SORT2_BLOCK, 8) k_sort2(const u32* __restrict__ coarse, const u32* __restrict__ P1,
                                                       const u32* __restrict__ total, int c, int lo_bits, int NH,
                                                       u32 sign_bit, int nblk, int nbins, u32 big_thresh,
-                                                      u32* __restrict__ hist, u32* __restrict__ sidx,
-                                                      u32* __restrict__ sbid) {
+                                                      u32* __restrict__ hist, uint2* __restrict__ sent) {
   __shared__ u32 cnt[256];   // per-tile bucket counts (first: the bin-wide counts of a multi-tile bin)
   __shared__ u32 cur[256];   // next output position of every bucket
   __shared__ u32 lcur[256], gdelta[256];
@@ -612,8 +612,7 @@ static __global__ void __launch_bounds__(SORT2_BLOCK, 8) k_sort2(const u32* __re
       const u32 v = stage[j];
       const u32 lo = v & lo_mask;
       const u32 pos = j + gdelta[lo];
-      sidx[pos] = (v >> 8) | ((v & sign_bit) << 24);
-      sbid[pos] = bucket0 + lo;
+      sent[pos] = make_uint2((v >> 8) | ((v & sign_bit) << 24), bucket0 + lo);
     }
     block_sync();
   }
@@ -632,7 +631,7 @@ constexpr int SORTS_MAX_N = SORTS_BLOCK * SORTS_PER;
 constexpr int SORTS_MAX_CB = 10;
 static __global__ void __launch_bounds__(SORTS_BLOCK) k_sort_small(const uint16_t* __restrict__ digits, int n, int cb, int sd,
                                                                    u32* __restrict__ total, u32* __restrict__ hist,
-                                                                   u32* __restrict__ sidx, u32* __restrict__ sbid) {
+                                                                   uint2* __restrict__ sent) {
   __shared__ u32 cnt[1 << SORTS_MAX_CB];
   __shared__ u32 off[1 << SORTS_MAX_CB];
   __shared__ u32 wsum[SORTS_BLOCK / 64];
@@ -680,8 +679,7 @@ static __global__ void __launch_bounds__(SORTS_BLOCK) k_sort_small(const uint16_
     if (bk[k] == BID_NONE) continue;
     const u32 b = bk[k] & 0x7fffffffu;
     const u32 pos = base + off[b] + rk[k];
-    sidx[pos] = (u32)(k * SORTS_BLOCK + t) | (bk[k] & SIDX_NEG);
-    sbid[pos] = ((u32)w << cb) | b;
+    sent[pos] = make_uint2((u32)(k * SORTS_BLOCK + t) | (bk[k] & SIDX_NEG), ((u32)w << cb) | b);
   }
 }
 
@@ -1005,6 +1003,12 @@ segreduce_lane(const int t, const u32* __restrict__ bid_in, const u32* __restric
   // 0 means every bucket is already complete and the level has nothing to do
   if (!FIRST && *d_count == 0) return;
   const long long n_in = FIRST ? (long long)(*d_count) : (long long)n_in_static;
+  // level 1 reads (index, bucket id) pairs (handed over through idx_in); the generic levels a plain id array
+  const uint2* ent = reinterpret_cast<const uint2*>(idx_in);
+  auto bid_at = [&](long long p) -> u32 {
+    if constexpr (FIRST) return ent[p].y;
+    else return bid_in[p];
+  };
   const long long s = (long long)t * L;
   u32 head_bid = BID_NONE, tail_bid = BID_NONE;
   bool live = s < n_in;
@@ -1016,10 +1020,10 @@ segreduce_lane(const int t, const u32* __restrict__ bid_in, const u32* __restric
   }
   if (live) {
     const long long e = (s + L < n_in) ? (s + L) : n_in;
-    const u32 first_bid = bid_in[s];
-    const bool cb = (s > 0) && (bid_in[s - 1] == first_bid) && (first_bid != BID_NONE);
-    const u32 last_bid = bid_in[e - 1];
-    const bool cf = (e < n_in) && (bid_in[e] == last_bid) && (last_bid != BID_NONE);
+    const u32 first_bid = bid_at(s);
+    const bool cb = (s > 0) && (bid_at(s - 1) == first_bid) && (first_bid != BID_NONE);
+    const u32 last_bid = bid_at(e - 1);
+    const bool cf = (e < n_in) && (bid_at(e) == last_bid) && (last_bid != BID_NONE);
     u32 cur = BID_NONE;
     bool cur_cb = false;
     using Acc = std::conditional_t<(FIRST && CV::LDS_ACC), RunAccLds<CV>, RunAcc<CV, FIRST>>;
@@ -1037,10 +1041,10 @@ segreduce_lane(const int t, const u32* __restrict__ bid_in, const u32* __restric
       // again): a load under `if (p + 1 < e)` makes every look-ahead register a phi of "loaded" and "kept", and the
       // compiler then carries the whole 16-word record and the index words through ~45 v_mov per addition.
       const u32 n_e = (u32)(e - s);         // entries of this chunk (<= L)
-      const u32* idx_c = idx_in + s;
-      const u32* bid_c = bid_in + s;
-      u32 v_cur = idx_c[0];
-      u32 v_next = idx_c[n_e > 1 ? 1 : 0];
+      const uint2* ent_c = ent + s;
+      const uint2 e_first = ent_c[0];
+      uint2 e_next = ent_c[n_e > 1 ? 1 : 0];
+      u32 v_cur = e_first.x;
       typename Acc::Raw r = Acc::load_raw(pts_in, v_cur);
       u32 b_cur = first_bid;
       for (u32 k = 0; k < n_e; k++) {
@@ -1050,13 +1054,14 @@ segreduce_lane(const int t, const u32* __restrict__ bid_in, const u32* __restric
           if constexpr (LAZY) return Acc::decode_unsigned(r);
           else return Acc::decode(r, v_cur);
         }();
-        // request entry k + 1's record and bucket id and entry k + 2's index word; consumed one iteration later
-        const u32 k1 = (k + 1 < n_e) ? k + 1 : n_e - 1;
+        // request entry k + 1's record (its pair arrived one iteration ago) and the pair of entry k + 2; both are
+        // consumed one iteration later
         const u32 k2 = (k + 2 < n_e) ? k + 2 : n_e - 1;
-        r = Acc::load_raw(pts_in, v_next);
-        b_cur = bid_c[k1];
-        v_cur = v_next;
-        v_next = idx_c[k2];
+        const uint2 en = e_next;
+        r = Acc::load_raw(pts_in, en.x);
+        b_cur = en.y;
+        v_cur = en.x;
+        e_next = ent_c[k2];
         if (b != cur) {
           if (cur != BID_NONE) {
             if (cur_cb) {

@@ -224,7 +224,8 @@ struct MsmLayout {
   u32 *hist, *C1, *P1, *blocksum, *total;  // total[0] = sorted entries, total[1] = live partial slots
   uint16_t* digits;
   uint8_t* neg_flags;  // GLV: sign of each half scalar
-  u32 *coarse, *sidx, *sbid;
+  u32* coarse;
+  uint2* sent;   // sorted entries: (base index | sign << 31, bucket id), bucket-major
   BigBins* bigbins;
   u32* bigT;
   size_t big_items_max;
@@ -266,8 +267,7 @@ MsmLayout make_layout3(const MsmPlan& p, void* sorted, void* sort_ws, void* accu
   if (prepared) L.aff = (u32*)prepared;  // affine records kept across MSMs (ozk_var_msm_prepare_dev)
   L.hist = a.take<u32>(L.NB);
   L.total = a.take<u32>(4);
-  L.sidx = a.take<u32>(L.cap);
-  L.sbid = a.take<u32>(L.cap + 1);
+  L.sent = a.take<uint2>(L.cap + 1);
   a.take<u32>(64);
   Bump b(sort_ws, ~(size_t)0);
   L.C1 = b.take<u32>(L.nC1);
@@ -423,8 +423,7 @@ int var_msm_sort(const void* d_bases, const void* d_scalars, int n, void* sorted
   }
   if (n <= SORTS_MAX_N && p.cb <= SORTS_MAX_CB && env_int("OZK_MSM_SMALL_SORT", 1)) {
     // a small MSM: the whole sort in one launch (msm_var.cuh k_sort_small); L.total[0] was zeroed above
-    hipLaunchKernelGGL(k_sort_small, dim3(p.W), dim3(SORTS_BLOCK), 0, st, L.digits, n, p.cb, p.sd, L.total, L.hist, L.sidx,
-                       L.sbid);
+    hipLaunchKernelGGL(k_sort_small, dim3(p.W), dim3(SORTS_BLOCK), 0, st, L.digits, n, p.cb, p.sd, L.total, L.hist, L.sent);
     if (order_ev && env_int("OZK_MSM_ORDER", 1)) OZK_HIP(hipStreamWaitEvent(st, order_ev, 0));
     OZK_HIP(hipGetLastError());
     return OZK_OK;
@@ -451,7 +450,7 @@ int var_msm_sort(const void* d_bases, const void* d_scalars, int n, void* sorted
     return fail(OZK_E_INVALID, "window plan c=%d (W=%d) at n=%d can produce more than %d oversized sort bins",
                 p.c, p.W, p.n_in, SORTBIG_MAXBINS);
   hipLaunchKernelGGL(k_sort2, dim3(nbins), dim3(SORT2_BLOCK), 0, st, L.coarse, L.P1, L.total, p.cb, L.lo_bits, L.NH,
-                     sign_bit, L.nblk, nbins, big_thresh, L.hist, L.sidx, L.sbid);
+                     sign_bit, L.nblk, nbins, big_thresh, L.hist, L.sent);
   // Ordering hint for pipelined MSMs (see ozk_var_msm_tail_ordered_dev): everything up to here may
   // overlap the previous MSM's window-sum levels; the bucket accumulation that follows fills every
   // SIMD's register file, so the previous MSM's single-wave Horner kernel has to be resident first.
@@ -463,7 +462,7 @@ int var_msm_sort(const void* d_bases, const void* d_scalars, int n, void* sorted
   hipLaunchKernelGGL(k_sortbig_scan, dim3(SORTBIG_MAXBINS), dim3(256), 0, st, L.bigbins, L.bigT, p.cb, L.lo_bits, L.NH,
                      L.hist);
   hipLaunchKernelGGL(k_sortbig_scatter, dim3(1024), dim3(SORT_BLOCK), 0, st, L.coarse, L.bigbins, L.bigT, p.cb,
-                     L.lo_bits, sign_bit, L.NH, L.sidx, L.sbid);
+                     L.lo_bits, sign_bit, L.NH, L.sent);
   OZK_HIP(hipGetLastError());
   return OZK_OK;
 }
@@ -509,7 +508,7 @@ int var_msm_accum(int n, void* sorted, size_t sorted_bytes, void* accum_ws, size
       OZK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)acc_lds));
     hipExtLaunchKernelGGL(kern, dim3((unsigned)((lanes + TB - 1) / TB)), dim3(TB), (uint32_t)acc_lds, st,
                           prof ? prof_e0 : (hipEvent_t) nullptr, prof ? prof_e1 : (hipEvent_t) nullptr, 0u,
-                          (const u32*)L.sbid, (const u32*)L.sidx, (const u32*)L.aff, (const u32*)L.total, 0, p.L1,
+                          (const u32*)nullptr, (const u32*)L.sent, (const u32*)L.aff, (const u32*)L.total, 0, p.L1,
                           L.buckets, L.slot_bid[0], L.slot_pts[0], (int)lanes, clk);
     return OZK_OK;
   };
