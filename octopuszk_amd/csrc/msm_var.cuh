@@ -799,6 +799,25 @@ struct RunAcc<CV, true> {
     for (int k = 0; k < IO::AFF_WORDS / 4; k++) r.w[k] = p[k];
     return r;
   }
+  // The same through a BUFFER RESOURCE (round 4): AFF_WORDS / 4 buffer_load_dwordx4 off ONE 32-bit offset register with
+  // immediate offsets, instead of what hipcc makes of the pointer form — for the 64-byte G1 record five global loads of
+  // 8 / 16 / 16 / 12 / 16 bytes (it scalarises the uint4 loads and re-vectorises them) behind 64-bit address
+  // arithmetic.  On the rebuilt loop: 1.10 -> 1.05 ms per 16.78 M additions (profiles/r04_ubench_l1loop.txt,
+  // variant K).  The table is at most 2^24 records of 64 / 128 bytes: offsets fit 32 bits.
+  typedef int v4i_ __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ __amdgpu_buffer_rsrc_t table_rsrc(const u32* pts) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)pts, 0, (int)0xffffffffu, 0x00020000);   // raw, no swizzle, no range clip
+  }
+  static __device__ __forceinline__ Raw load_raw_buf(__amdgpu_buffer_rsrc_t rs, u32 v) {
+    Raw r;
+    const int off = (int)((v & ~SIDX_NEG) * (u32)(IO::AFF_WORDS * 4));
+#pragma unroll
+    for (int k = 0; k < IO::AFF_WORDS / 4; k++) {
+      const v4i_ w4 = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16 * k, 0, 0);
+      r.w[k] = make_uint4((u32)w4.x, (u32)w4.y, (u32)w4.z, (u32)w4.w);
+    }
+    return r;
+  }
   static __device__ __forceinline__ Aff<EA> decode(const Raw& r, u32 v) {
     u32 w[IO::AFF_WORDS];
 #pragma unroll
@@ -890,6 +909,8 @@ struct RunAccLds {
   }
   using Raw = typename RunAcc<CV, true>::Raw;
   static __device__ __forceinline__ Raw load_raw(const u32* pts, u32 v) { return RunAcc<CV, true>::load_raw(pts, v); }
+  static __device__ __forceinline__ __amdgpu_buffer_rsrc_t table_rsrc(const u32* pts) { return RunAcc<CV, true>::table_rsrc(pts); }
+  static __device__ __forceinline__ Raw load_raw_buf(__amdgpu_buffer_rsrc_t rs, u32 v) { return RunAcc<CV, true>::load_raw_buf(rs, v); }
   static __device__ __forceinline__ Aff<EA> decode(const Raw& r, u32 v) { return RunAcc<CV, true>::decode(r, v); }
   __device__ __forceinline__ void start(const u32* pts, const u32* idx, long long p) {
     start_q(load_signed(pts, idx, p));
@@ -1045,7 +1066,8 @@ segreduce_lane(const int t, const u32* __restrict__ bid_in, const u32* __restric
       const uint2 e_first = ent_c[0];
       uint2 e_next = ent_c[n_e > 1 ? 1 : 0];
       u32 v_cur = e_first.x;
-      typename Acc::Raw r = Acc::load_raw(pts_in, v_cur);
+      const __amdgpu_buffer_rsrc_t table = Acc::table_rsrc(pts_in);
+      typename Acc::Raw r = Acc::load_raw_buf(table, v_cur);
       u32 b_cur = first_bid;
       for (u32 k = 0; k < n_e; k++) {
         const u32 b = b_cur;
@@ -1058,7 +1080,7 @@ segreduce_lane(const int t, const u32* __restrict__ bid_in, const u32* __restric
         // consumed one iteration later
         const u32 k2 = (k + 2 < n_e) ? k + 2 : n_e - 1;
         const uint2 en = e_next;
-        r = Acc::load_raw(pts_in, en.x);
+        r = Acc::load_raw_buf(table, en.x);
         b_cur = en.y;
         v_cur = en.x;
         e_next = ent_c[k2];

@@ -75,16 +75,33 @@ __global__ void __launch_bounds__(256) k_loop(const u32* __restrict__ idx, const
   if constexpr (MODE == 7) r80 = load80(v_cur);
   u32 b_cur = bid_c[0];
   // MODE 8: entries (index, bucket id) interleaved: ONE 8-byte load two entries ahead instead of two 4-byte loads
-  const uint2* ent_c = ent + (size_t)t * L;
+  const size_t n_lanes_all = (size_t)gridDim.x * blockDim.x;
+  const uint2* ent_c = (MODE == 9) ? ent + t : ent + (size_t)t * L;
+  const size_t estride = (MODE == 9) ? n_lanes_all : 1;
   uint2 e_next = make_uint2(0, 0);
-  if constexpr (MODE == 8) {
+  if constexpr (MODE == 8 || MODE == 9 || MODE == 10) {
     const uint2 e0 = ent_c[0];
-    e_next = ent_c[1];
+    e_next = ent_c[estride];
     v_cur = e0.x;
     b_cur = e0.y;
     v_next = e_next.x;
     r = Acc::load_raw(pts, v_cur);
   }
+  // MODE 10: the record through a buffer resource: four buffer_load_dwordx4 off ONE 32-bit offset register (immediate
+  // offsets 0 / 16 / 32 / 48) instead of the five odd-sized global loads and the 64-bit address arithmetic hipcc makes
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)pts, 0, (int)0x7fffffff, 0x00020000);
+  auto buf_load = [&](u32 v) {
+    typename Acc::Raw x;
+    const int off = (int)((v & ~SIDX_NEG) << 6);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const v4i w4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16 * q, 0, 0);
+      x.w[q] = make_uint4((u32)w4.x, (u32)w4.y, (u32)w4.z, (u32)w4.w);
+    }
+    return x;
+  };
+  if constexpr (MODE == 10) r = buf_load(v_cur);
   u32 cur = BID_NONE;
   Aff<EA> qfix = Acc::decode_unsigned(r);
   u32 sink = 0;
@@ -106,22 +123,23 @@ __global__ void __launch_bounds__(256) k_loop(const u32* __restrict__ idx, const
     if constexpr (MODE == 4) sink ^= r.w[0].x ^ r.w[1].y ^ r.w[2].z ^ r.w[3].w;
     const u32 k1 = (k + 1 < n_e) ? k + 1 : n_e - 1;
     const u32 k2 = (k + 2 < n_e) ? k + 2 : n_e - 1;
-    if constexpr (MODE == 8) {
+    if constexpr (MODE == 8 || MODE == 9 || MODE == 10) {
       const uint2 en = e_next;            // entry k + 1: requested one iteration ago
-      r = Acc::load_raw(pts, en.x);
+      if constexpr (MODE == 10) r = buf_load(en.x);
+      else r = Acc::load_raw(pts, en.x);
       b_cur = en.y;
       v_next = en.x;
-      e_next = ent_c[k2];                 // entry k + 2: ONE 8-byte load
+      e_next = ent_c[(size_t)k2 * estride];   // entry k + 2: ONE 8-byte load
     } else if constexpr (MODE == 7) r80 = load80(v_next);
     else if constexpr (MODE == 6) lds_issue(v_next, (k + 1u) & 1u);
-    else if constexpr (MODE != 0 && MODE != 5 && MODE != 8) r = Acc::load_raw(pts, v_next);
+    else if constexpr (MODE != 0 && MODE != 5 && MODE != 8 && MODE != 9 && MODE != 10) r = Acc::load_raw(pts, v_next);
     if constexpr (MODE == 3) b_cur = bid_c[k1];
     v_cur = v_next;
-    if constexpr (MODE == 8) {
+    if constexpr (MODE == 8 || MODE == 9 || MODE == 10) {
     } else if constexpr (MODE != 0 && MODE != 5) v_next = idx_c[k2];
     else v_next = v_next * 1664525u + 1013904223u;
-    if ((MODE == 3 || MODE == 8) ? (b != cur) : ((MODE == 4 || MODE == 5) ? false : (k == 0))) {
-      if ((MODE == 3 || MODE == 8) && cur != BID_NONE) acc.store(buckets + (size_t)cur * IO::REC_WORDS);
+    if ((MODE == 3 || MODE == 8 || MODE == 9 || MODE == 10) ? (b != cur) : ((MODE == 4 || MODE == 5) ? false : (k == 0))) {
+      if ((MODE == 3 || MODE == 8 || MODE == 9 || MODE == 10) && cur != BID_NONE) acc.store(buckets + (size_t)cur * IO::REC_WORDS);
       cur = b;
       acc.start_signed(q, negate);
     } else {
@@ -188,6 +206,14 @@ int main() {
     for (size_t i = 0; i < NE; i++) h[i] = make_uint2(h_idx[i], h_bid[i]);
     (void)hipMemcpy(d_ent, h.data(), NE * 8, hipMemcpyHostToDevice);
   }
+  uint2* d_ent_t;
+  (void)hipMalloc(&d_ent_t, NE * 8);
+  {
+    std::vector<uint2> h(NE);
+    for (size_t tt = 0; tt < (size_t)lanes; tt++)
+      for (int k = 0; k < L; k++) h[(size_t)k * lanes + tt] = make_uint2(h_idx[tt * L + k], h_bid[tt * L + k]);
+    (void)hipMemcpy(d_ent_t, h.data(), NE * 8, hipMemcpyHostToDevice);
+  }
   u32* d_pts80;
   (void)hipMalloc(&d_pts80, NP * 80);
   {
@@ -196,18 +222,22 @@ int main() {
     (void)hipMemcpy(d_pts80, h.data(), NP * 80, hipMemcpyHostToDevice);
   }
   const size_t lds = 41216;
-  const char* names[9] = {"A formula, q in registers (same q: +-q cancels, INVALID)", "B + gather (random, one entry ahead)", "C + gather (sequential indices)",
+  const char* names[11] = {"A formula, q in registers (same q: +-q cancels, INVALID)", "B + gather (random, one entry ahead)", "C + gather (sequential indices)",
                           "D + run logic and run-end stores (random gather)", "E gather issued, record unused; formula on a register q",
                           "F no loads, q changed by register ops every entry",
                           "G = B with the record prefetched into LDS (global_load_lds_dwordx4)",
                           "H = B over UNPACKED 80-byte records (no unpacking, 25 % more bytes)",
-                          "I = D with (index, bucket id) interleaved: one 8-byte load per entry instead of two 4-byte ones"};
-  for (int mode = 0; mode < 9; mode++) {
+                          "I = D with (index, bucket id) interleaved: one 8-byte load per entry instead of two 4-byte ones",
+                          "J = I with the entry stream transposed (entry k of lane t at [k][t]): coalesced entry reads",
+                          "K = I with the record by four buffer_load_dwordx4 off one 32-bit offset"};
+  for (int mode = 0; mode < 11; mode++) {
     double ms = mode == 0   ? timeit([&] { hipLaunchKernelGGL(k_loop<0>, dim3(blocks), dim3(256), lds, 0, d_idx, d_bid, d_pts, d_buckets, d_out, L); })
                 : mode == 1 ? timeit([&] { hipLaunchKernelGGL(k_loop<1>, dim3(blocks), dim3(256), lds, 0, d_idx, d_bid, d_pts, d_buckets, d_out, L); })
                 : mode == 2 ? timeit([&] { hipLaunchKernelGGL(k_loop<1>, dim3(blocks), dim3(256), lds, 0, d_seq, d_bid, d_pts, d_buckets, d_out, L); })
                 : mode == 4 ? timeit([&] { hipLaunchKernelGGL(k_loop<4>, dim3(blocks), dim3(256), lds, 0, d_idx, d_bid, d_pts, d_buckets, d_out, L); })
                 : mode == 5 ? timeit([&] { hipLaunchKernelGGL(k_loop<5>, dim3(blocks), dim3(256), lds, 0, d_idx, d_bid, d_pts, d_buckets, d_out, L); })
+                : mode == 10 ? timeit([&] { hipLaunchKernelGGL(k_loop<10>, dim3(blocks), dim3(256), lds, 0, d_idx, d_bid, d_pts, d_buckets, d_out, L, d_ent); })
+                : mode == 9 ? timeit([&] { hipLaunchKernelGGL(k_loop<9>, dim3(blocks), dim3(256), lds, 0, d_idx, d_bid, d_pts, d_buckets, d_out, L, d_ent_t); })
                 : mode == 8 ? timeit([&] { hipLaunchKernelGGL(k_loop<8>, dim3(blocks), dim3(256), lds, 0, d_idx, d_bid, d_pts, d_buckets, d_out, L, d_ent); })
                 : mode == 7 ? timeit([&] { hipLaunchKernelGGL(k_loop<7>, dim3(blocks), dim3(256), lds, 0, d_idx, d_bid, d_pts80, d_buckets, d_out, L); })
                 : mode == 6 ? timeit([&] { hipLaunchKernelGGL(k_loop<6>, dim3(blocks), dim3(256), lds, 0, d_idx, d_bid, d_pts, d_buckets, d_out, L); })
