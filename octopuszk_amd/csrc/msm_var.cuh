@@ -1238,8 +1238,12 @@ k_runmerge(const u32* __restrict__ bid_in, const u32* __restrict__ pts, int n_sl
       } else if (s == x) {  // owner of the run: sum it
         // level-1 pieces are all XYZZ records (the neutral placeholder of a chunk cut on both sides
         // included): 12M + 2S general additions, no conversion
+        // A run is [tail piece of lane t | head piece of lane t + 1 | (placeholder of t + 1 | head piece of t + 2)* ]:
+        // it starts at an odd slot (a tail piece), every other odd slot inside it is the infinity placeholder of a
+        // chunk cut on both sides, every even slot a head piece — so only the even slots are added (round 4: a run of
+        // four slots costs two additions instead of three, one of them with infinity; almost every wave holds one)
         Xyzz<CV> acc = IO::load_xyzz(pts + (size_t)s * IO::REC_WORDS);
-        for (int q = s + 1; q <= e; q++) acc = xyzz_add(acc, IO::load_xyzz(pts + (size_t)q * IO::REC_WORDS));
+        for (int q = s + 1; q <= e; q += 2) acc = xyzz_add(acc, IO::load_xyzz(pts + (size_t)q * IO::REC_WORDS));
         IO::store_rec_xyzz(acc, buckets + (size_t)bx * IO::REC_WORDS);
       }
     }
