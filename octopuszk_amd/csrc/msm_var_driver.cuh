@@ -140,7 +140,9 @@ static MsmPlan make_plan(int n) {
     long long l1 = per_bucket * 5 / 16;
     // at least 40 entries per lane; 56 from 2^20 points on (fewer pieces for the run merge: pipelined 2^20 G1 +1.5 %,
     // G2 2^20 -0.15 ms, a 2^20-constraint proof -0.3 ms; smaller MSMs lose 30-100 us with it)
-    long long l1_min = env_int("OZK_MSM_L1_MIN", p.n >= (1 << 20) ? 56 : 40);
+    // (round 4, with the 8-byte entry stream: 52 measures 0.8 % above 56 and 48 on the 100-step bench, twice on one box —
+    // 48 / 52 / 56 / 60 / 64 / 72 -> 702 / 709 / 703 / 694 / 670 / 637 Mscalar-mul/s, profiles/r04_l1_chunk_sweep.txt)
+    long long l1_min = env_int("OZK_MSM_L1_MIN", p.n >= (1 << 20) ? 52 : 40);
     // SMALL MSMs (round 4): below ~2^17 pairs the launch does not fill the chip — 818 lanes at 2^10 — and the level is
     // a chain of L1 dependent additions on lone waves (~5 us each): 200 us of a 0.94 ms MSM at n = 2^10
     // (profiles/r04_small_n_probe.txt).  Shorter chunks, down to 8 entries, as long as (a) the lanes still fit one
