@@ -59,7 +59,7 @@ d_out = torch.zeros(192, dtype=torch.uint8, device="cuda")
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 a256 = lambda x: (x + 255) & ~255
 cap = ne * W
-off_hist = a256(ne * 64); off_total = a256(off_hist + NB * 4); off_sidx = a256(off_total + 16); off_sbid = a256(off_sidx + cap * 4)
+off_hist = a256(ne * 64); off_total = a256(off_hist + NB * 4); off_sent = a256(off_total + 16)   # (round 4: the sorted entries are 8-byte pairs (index | sign << 31, bucket id))
 REC = 40
 for attempt in range(12):
     d_sorted.zero_(); d_sortws.zero_(); d_acc.fill_(fillv); d_tail.fill_(fillv)
@@ -67,14 +67,14 @@ for attempt in range(12):
     torch.cuda.synchronize()
     total = int(d_sorted[off_total:off_total + 4].view(torch.int32)[0])
     hist_sort = d_sorted[off_hist:off_hist + NB * 4].view(torch.int32).cpu().numpy().copy()
-    sbid0 = d_sorted[off_sbid:off_sbid + total * 4].view(torch.int32).cpu().numpy().astype(np.int64) & 0xffffffff
-    sidx0 = d_sorted[off_sidx:off_sidx + total * 4].view(torch.int32).cpu().numpy().astype(np.int64) & 0xffffffff
+    sbid0 = d_sorted[off_sent:off_sent + total * 8].view(torch.int32).cpu().numpy().astype(np.int64).reshape(-1, 2)[:, 1] & 0xffffffff
+    sidx0 = d_sorted[off_sent:off_sent + total * 8].view(torch.int32).cpu().numpy().astype(np.int64).reshape(-1, 2)[:, 0] & 0xffffffff
     ozk.check(L.ozk_var_msm_accum_dev(n, 1, ptr(d_sorted), sb.value, ptr(d_acc), ab.value, ptr(d_tail), tb, st))
     torch.cuda.synchronize()
     recs = d_tail[:NB * REC * 4].view(torch.int32).cpu().numpy().astype(np.int64).reshape(NB, REC) & 0xffffffff
     hist_t = d_tail[NB * REC * 4:NB * REC * 4 + NB * 4].view(torch.int32).cpu().numpy().copy()
     hist_after = d_sorted[off_hist:off_hist + NB * 4].view(torch.int32).cpu().numpy().copy()
-    sbid1 = d_sorted[off_sbid:off_sbid + total * 4].view(torch.int32).cpu().numpy().astype(np.int64) & 0xffffffff
+    sbid1 = d_sorted[off_sent:off_sent + total * 8].view(torch.int32).cpu().numpy().astype(np.int64).reshape(-1, 2)[:, 1] & 0xffffffff
     ozk.check(L.ozk_var_msm_tail_dev(n, 1, ptr(d_tail), tb, ptr(d_out), st))
     torch.cuda.synchronize()
     ok = bytes(d_out.cpu().numpy()) == want

@@ -52,7 +52,7 @@ d_sortws = torch.zeros(swb.value, dtype=torch.uint8, device="cuda")
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 NB = W << cb; cap = ne * W
 a256 = lambda x: (x + 255) & ~255
-off_hist = a256(ne * 64); off_total = a256(off_hist + NB * 4); off_sidx = a256(off_total + 16); off_sbid = a256(off_sidx + cap * 4)
+off_hist = a256(ne * 64); off_total = a256(off_hist + NB * 4); off_sent = a256(off_total + 16)   # (round 4: the sorted entries are 8-byte pairs (index | sign << 31, bucket id))
 want_total = int((exp_b >= 0).sum())
 for rep in range(int(os.environ.get("DIAG_REPS", "12"))):
     d_sorted.zero_(); d_sortws.zero_()
@@ -62,8 +62,8 @@ for rep in range(int(os.environ.get("DIAG_REPS", "12"))):
     msgs = []
     if total != want_total: msgs.append("total %d != %d" % (total, want_total))
     m = min(total, cap)
-    sidx = d_sorted[off_sidx:off_sidx + m * 4].view(torch.int32).cpu().numpy().astype(np.int64) & 0xffffffff
-    sbid = d_sorted[off_sbid:off_sbid + m * 4].view(torch.int32).cpu().numpy().astype(np.int64) & 0xffffffff
+    sidx = d_sorted[off_sent:off_sent + m * 8].view(torch.int32).cpu().numpy().astype(np.int64).reshape(-1, 2)[:, 0] & 0xffffffff
+    sbid = d_sorted[off_sent:off_sent + m * 8].view(torch.int32).cpu().numpy().astype(np.int64).reshape(-1, 2)[:, 1] & 0xffffffff
     hist = d_sorted[off_hist:off_hist + NB * 4].view(torch.int32).cpu().numpy()
     v = sidx & 0xffffff; s = (sidx >> 31) & 1; w = sbid >> cb; b = sbid & ((1 << cb) - 1)
     inr = (v < ne) & (w < W)
