@@ -125,6 +125,10 @@ def main():
     ap.add_argument("--in-flight", type=int, default=None,
                     help="MSMs in flight (default: 3 for --schedule streams, 2 for pipeline; 1 = strictly serial steps)")
     ap.add_argument("--tail-streams", type=int, default=2, help="pipeline3: streams the tails alternate on")
+    ap.add_argument("--tail-cus", type=int, default=int(os.environ.get("OZK_BENCH_TAIL_CUS", "0")),
+                    help="pipeline3: confine the tail streams to this many compute units and the accumulate stream to "
+                         "the others (device.VarMsmPipeline3(tail_cus=...)); the steps then run on a side stream, "
+                         "because CU-masked streams synchronise with the null stream.  0 = no partition")
     ap.add_argument("--schedule", choices=["streams", "pipeline", "pipeline3"], default=os.environ.get("OZK_BENCH_SCHEDULE", "pipeline3"),
                     help="pipeline3 (default): sort of MSM k+1 | bucket accumulation of MSM k | tail of MSM k-1 on their own "
                          "streams (device.VarMsmPipeline3); "
@@ -187,7 +191,7 @@ def main():
     sc_host = rand_scalars(n, scalar_seed(rank))
     scalars = torch.from_numpy(sc_host).cuda()
     if args.schedule == "pipeline3" and args.in_flight >= 2:
-        pipe = dev.VarMsmPipeline3(n, 1, depth=args.in_flight, tail_streams=args.tail_streams)
+        pipe = dev.VarMsmPipeline3(n, 1, depth=args.in_flight, tail_streams=args.tail_streams, tail_cus=args.tail_cus)
     else:
         pipe = dev.VarMsmPipeline(n, 1, depth=max(1, args.in_flight))
     ozk.check(L.ozk_prof_enable(2))   # (calibrates and allocates; enabled again, cleared, in front of the timed steps)
@@ -239,10 +243,19 @@ def main():
                                                    dev.points_sum, 1, always_collective=force_coll)
         return res
 
+    partitioned = isinstance(pipe, dev.VarMsmPipeline3) and pipe.tail_cus > 0
+    sort_stream = torch.cuda.Stream() if partitioned else None
+
     def run_steps(k):
         """k complete MSMs; step i's tail overlaps step i+1's head (args.in_flight > 1)."""
         if args.schedule == "streams":
             return run_steps_streams(k)
+        if partitioned:   # (the sort stage on a stream of this process's own: see --tail-cus)
+            with torch.cuda.stream(sort_stream):
+                return run_steps_on_current_stream(k)
+        return run_steps_on_current_stream(k)
+
+    def run_steps_on_current_stream(k):
         res, prev = None, None
         three = isinstance(pipe, dev.VarMsmPipeline3) and os.environ.get("OZK_BENCH_LAST_LATENCY", "1") != "0"
         for i in range(k):
@@ -441,6 +454,8 @@ def main():
                            "n_per_gpu": n, "window_bits": wb.value, "windows": wn.value, "glv": bool(glv),
                            "prepared_bases": bool(args.prepared),
                            "msms_in_flight": max(1, args.in_flight), "schedule": args.schedule,
+                           "cu_partition": ({"tail": pipe.tail_cus, "accumulate": int(L.ozk_device_cu_count()) - pipe.tail_cus}
+                                            if partitioned else None),
                            "single_msm_latency_ms": round(single_ms, 3),
                            "three_streams_Mscalar_mul_s": streams3,
                            "result_hex": result_bytes.hex(),

@@ -50,6 +50,14 @@ int ozk_version(void);
 /* number of visible HIP devices (0 if none); `taskID % count` selects the device as
  * the reference does (algebra_msm_VariableBaseMSM.cu:1249-1257). */
 int ozk_device_count(void);
+/* Streams confined to compute units [first_cu, first_cu + n_cus) of the current device (hipExtStreamCreateWithCUMask;
+ * ozk_device_cu_count() = the device's compute units, 256 on an MI355X), for callers that partition the chip between
+ * the stages of consecutive MSMs (device.VarMsmPipeline3(tail_cus=...): tails on a few units, the accumulation on the
+ * rest).  Such a stream is a BLOCKING stream: it synchronises with the null stream, so nothing of a schedule that
+ * uses it may run there.  ozk_stream_destroy gives it back. */
+int ozk_device_cu_count(void);
+int ozk_stream_create_cu_range(int32_t first_cu, int32_t n_cus, void** stream);
+int ozk_stream_destroy(void* stream);
 /* The OZK_* tuning environment variables are read once per process and cached (a plan must not change
  * between the workspace-size query and the run); tests and tuning scripts call this after changing one. */
 int ozk_tuning_reload(void);
@@ -184,6 +192,14 @@ int ozk_var_msm_sort_prepared_dev(const void* d_prepared, const void* d_scalars,
 int ozk_var_msm_accum_prepared_dev(const void* d_prepared, int32_t n, int32_t type, void* d_sorted,
                                    size_t sorted_bytes, void* d_accum_ws, size_t accum_ws_bytes, void* d_tail,
                                    size_t tail_bytes, void* stream);
+/* ACCUMULATE in two parts, for a caller that keeps level 1 (the vector-ALU-bound kernel) back to back on one stream
+ * and runs the rest (run merge, the short generic levels, the copy of the bucket counts: ~0.1 ms of low-occupancy work)
+ * elsewhere: part 1 = level 1 only, part 2 = the rest (same arguments; it reads the sorted set and the accumulate
+ * scratch level 1 wrote, so neither may be reused before it has run), part 0 = both (= the two entry points above).
+ * d_prepared may be NULL (bases converted by the sort). */
+int ozk_var_msm_accum_part_dev(const void* d_prepared, int32_t n, int32_t type, void* d_sorted, size_t sorted_bytes,
+                               void* d_accum_ws, size_t accum_ws_bytes, void* d_tail, size_t tail_bytes,
+                               void* stream, int32_t part);
 size_t ozk_var_msm_head_workspace_bytes(int32_t n, int32_t type);
 size_t ozk_var_msm_tail_bytes(int32_t n, int32_t type);
 int ozk_var_msm_head_dev(const void* d_bases, const void* d_scalars, int32_t n, int32_t type,

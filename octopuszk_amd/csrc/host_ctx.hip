@@ -395,6 +395,41 @@ extern "C" int ozk_host_call_stats(double* stats9) {
   return OZK_OK;
 }
 
+// Streams confined to a range of compute units (round 4): the three-stage schedule's latency-bound tail kernels slow
+// the bucket accumulation by sitting on its SIMDs; a caller may give the tails `n_cus` units of their own and the
+// accumulation the rest (device.VarMsmPipeline3(tail_cus=...)).  The runtime creates such a stream as a BLOCKING stream:
+// it synchronises with the device's null stream, so the schedule that uses it must not run on the null stream.
+extern "C" int ozk_device_cu_count(void) {
+  using namespace ozk;
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+  return prop.multiProcessorCount;
+}
+extern "C" int ozk_stream_create_cu_range(int32_t first_cu, int32_t n_cus, void** stream) {
+  using namespace ozk;
+  hip_clear_stale();
+  if (!stream) return fail(OZK_E_INVALID, "null pointer argument");
+  const int total = ozk_device_cu_count();
+  if (total <= 0) return fail(OZK_E_NO_DEVICE, "no device properties");
+  if (first_cu < 0 || n_cus <= 0 || first_cu + n_cus > total)
+    return fail(OZK_E_INVALID, "compute-unit range [%d, %d) outside the device's %d", first_cu, first_cu + n_cus, total);
+  uint32_t mask[32] = {0};
+  const int words = (total + 31) / 32;
+  if (words > 32) return fail(OZK_E_INVALID, "%d compute units: mask too long", total);
+  for (int i = first_cu; i < first_cu + n_cus; i++) mask[i >> 5] |= 1u << (i & 31);
+  hipStream_t s = nullptr;
+  OZK_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask));
+  *stream = (void*)s;
+  return OZK_OK;
+}
+extern "C" int ozk_stream_destroy(void* stream) {
+  using namespace ozk;
+  if (!stream) return OZK_OK;
+  OZK_HIP(hipStreamDestroy((hipStream_t)stream));
+  return OZK_OK;
+}
+
 extern "C" int ozk_host_cache_release(void) {
   using namespace ozk;
   copy_shutdown();

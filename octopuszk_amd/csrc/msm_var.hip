@@ -272,6 +272,18 @@ int ozk_var_msm_accum_dev(int32_t n, int32_t type, void* d_sorted, size_t sorted
   return var_msm_accum<G2Cfg>(n, d_sorted, sorted_bytes, d_accum_ws, accum_ws_bytes, d_tail, tail_bytes,
                               (hipStream_t)stream);
 }
+int ozk_var_msm_accum_part_dev(const void* d_prepared, int32_t n, int32_t type, void* d_sorted, size_t sorted_bytes,
+                               void* d_accum_ws, size_t accum_ws_bytes, void* d_tail, size_t tail_bytes, void* stream,
+                               int32_t part) {
+  if (!d_sorted || !d_accum_ws || !d_tail) return fail(OZK_E_INVALID, "null pointer argument");
+  if (n <= 0 || n > (1 << 24)) return fail(OZK_E_INVALID, "batch_size %d out of range [1, 2^24]", n);
+  if (part < ACCUM_ALL || part > ACCUM_REST) return fail(OZK_E_INVALID, "part %d is not 0 (all), 1 (level 1) or 2 (rest)", part);
+  if (type == OZK_G1)
+    return var_msm_accum<G1Cfg>(n, d_sorted, sorted_bytes, d_accum_ws, accum_ws_bytes, d_tail, tail_bytes,
+                                (hipStream_t)stream, d_prepared, part);
+  return var_msm_accum<G2Cfg>(n, d_sorted, sorted_bytes, d_accum_ws, accum_ws_bytes, d_tail, tail_bytes,
+                              (hipStream_t)stream, d_prepared, part);
+}
 int ozk_var_msm_sort_prepared_dev(const void* d_prepared, const void* d_scalars, int32_t n, int32_t type, void* d_sorted,
                                   size_t sorted_bytes, void* d_sort_ws, size_t sort_ws_bytes, void* stream) {
   if (!d_prepared || !d_scalars || !d_sorted || !d_sort_ws) return fail(OZK_E_INVALID, "null pointer argument");

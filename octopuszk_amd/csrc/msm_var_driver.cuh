@@ -471,9 +471,13 @@ int var_msm_sort(const void* d_bases, const void* d_scalars, int n, void* sorted
 
 // ACCUMULATE stage: bucket accumulation, run merge, generic levels, first window-sum level.
 // Vector-ALU-bound.  Reads the sorted set, leaves W * 2^c / S window-sum elements in the tail buffers.
+// ACCUMULATE in two parts for callers that run them on different streams (ozk_var_msm_accum_part_dev): level 1 is
+// the vector-ALU-bound kernel; the REST (run merge, the short generic levels, the copy of the bucket counts) is 0.1 ms
+// of low-occupancy work that reads what level 1 wrote in the accumulate scratch and the sorted set.
+enum { ACCUM_ALL = 0, ACCUM_LEVEL1 = 1, ACCUM_REST = 2 };
 template <class CV>
 int var_msm_accum(int n, void* sorted, size_t sorted_bytes, void* accum_ws, size_t accum_ws_bytes, void* tail,
-                         size_t tail_bytes, hipStream_t st, const void* prepared = nullptr) {
+                         size_t tail_bytes, hipStream_t st, const void* prepared = nullptr, int part = ACCUM_ALL) {
   hip_clear_stale();   // (ozk_common.h: a stale error of the calling thread is not this call's)
   using CT = CV;  // (an out-of-line-multiplication variant for the tails measured 40 % slower)
   const MsmPlan p = plan_for<CV>(n);
@@ -487,6 +491,7 @@ int var_msm_accum(int n, void* sorted, size_t sorted_bytes, void* accum_ws, size
   const int TB = 256;
   // level 1 over the sorted entries
   size_t lanes = (L.cap + p.L1 - 1) / p.L1;
+  if (part != ACCUM_REST) {
   // optional timing of this launch (ProfState::claim): events that ride on the kernel's own dispatch packet
   // (hipExtLaunchKernelGGL start / stop events — separate hipEventRecord calls put two barrier packets around the
   // launch, which cost the three-stage schedule 8 % of its throughput: 637 -> 589 Mscalar-mul/s,
@@ -523,6 +528,11 @@ int var_msm_accum(int n, void* sorted, size_t sorted_bytes, void* accum_ws, size
     rc_l1 = launch_l1(k_segreduce<CV, true, false>);
   }
   if (rc_l1) return rc_l1;
+  }
+  if (part == ACCUM_LEVEL1) {
+    OZK_HIP(hipGetLastError());
+    return OZK_OK;
+  }
   // run merge: completes every bucket cut into at most RUN_MAX pieces; counts the surviving slots
   size_t n_in = 2 * lanes;
   hipLaunchKernelGGL((k_runmerge<CT>), dim3((unsigned)((lanes + TB - 1) / TB)), dim3(TB), 0, st, L.slot_bid[0],
@@ -937,7 +947,7 @@ int bases_msm(BasesHandle* h, const uint8_t* scalars, uint8_t* out) {
   PREFIX template int ozk::var_msm_sort<ozk::G2Cfg>(const void*, const void*, int, void*, size_t, void*, size_t,    \
                                                     hipStream_t, hipEvent_t, const void*);                          \
   PREFIX template int ozk::var_msm_accum<ozk::G2Cfg>(int, void*, size_t, void*, size_t, void*, size_t, hipStream_t,  \
-                                                     const void*);                                                   \
+                                                     const void*, int);                                              \
   PREFIX template int ozk::var_msm_head<ozk::G2Cfg>(const void*, const void*, int, void*, size_t, void*, size_t,     \
                                                     hipStream_t, hipEvent_t, const void*);                          \
   PREFIX template int ozk::var_msm_tail<ozk::G2Cfg>(int, void*, size_t, void*, hipStream_t, hipEvent_t, int);        \

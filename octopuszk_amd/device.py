@@ -1,6 +1,7 @@
 """Device-resident entry points on torch CUDA(HIP) tensors: torch is plumbing only (HBM
 buffers, streams, torch.distributed); all arithmetic is in libozk_hip.so."""
 import ctypes
+import os
 import sys
 
 import torch
@@ -140,9 +141,17 @@ class VarMsmPipeline3:
     accumulation blocks per CU (csrc/msm_var.cuh, k_sort2), which is what lets the multiplier run back to back.
     Same interface as VarMsmPipeline (submit -> ticket, result(ticket))."""
 
-    def __init__(self, n, type_=1, depth=3, tail_streams=2, device="cuda"):
+    def __init__(self, n, type_=1, depth=3, tail_streams=2, device="cuda", split_accum=None, tail_cus=None):
         L = _lib.load()
         ts = max(1, tail_streams)
+        # tail_cus = N > 0: the tail streams are confined to N compute units and the accumulate stream to the others
+        # (ozk_stream_create_cu_range): the latency-bound tail waves no longer sit on the accumulation's SIMDs.  Such
+        # streams are BLOCKING streams — they synchronise with the null stream — so submit() refuses to run on it.
+        self.tail_cus = int(os.environ.get("OZK_P3_TAIL_CUS", "0")) if tail_cus is None else int(tail_cus)
+        self._owned = []
+        # split_accum: level 1 alone on the accumulate stream, the rest of the stage (run merge, generic levels) at the
+        # head of the tail stream (ozk_var_msm_accum_part_dev); the accumulate scratch is then double-buffered too
+        self.split = bool(int(os.environ.get("OZK_P3_SPLIT_ACCUM", "0"))) if split_accum is None else bool(split_accum)
         # a result slot is always served by the same tail stream (slot = k mod depth, stream = k mod ts), so whatever a
         # caller enqueues on stream_of(ticket) after result(ticket) is ordered before the slot's next tail
         self.n, self.type, self.depth = n, type_, (max(2, depth) + ts - 1) // ts * ts
@@ -153,19 +162,51 @@ class VarMsmPipeline3:
         buf = lambda b: torch.empty(b, dtype=torch.uint8, device=device)
         self.sorted = [buf(self.sorted_bytes) for _ in range(2)]
         self.sort_ws, self.accum_ws = buf(self.sort_ws_bytes), buf(self.accum_ws_bytes)
+        self.accum_ws2 = [self.accum_ws, buf(self.accum_ws_bytes)] if self.split else None
+        self.rest_st = None
         self.tails = [buf(self.tail_bytes) for _ in range(self.depth)]
         self.outs = [torch.zeros(192 if type_ == 1 else 384, dtype=torch.uint8, device=device) for _ in range(self.depth)]
-        self.acc = torch.cuda.Stream(device=device)
-        self.tail_st = [torch.cuda.Stream(device=device) for _ in range(ts)]
+        if self.tail_cus > 0:
+            total = int(L.ozk_device_cu_count())
+            if not 0 < self.tail_cus < total:
+                raise ValueError(f"tail_cus={self.tail_cus}: the device has {total} compute units")
+
+            def confined(first, count):
+                h = ctypes.c_void_p()
+                _lib.check(L.ozk_stream_create_cu_range(first, count, ctypes.byref(h)))
+                self._owned.append(h.value)
+                return torch.cuda.ExternalStream(h.value)
+            self.acc = confined(self.tail_cus, total - self.tail_cus)
+            self.tail_st = [confined(0, self.tail_cus) for _ in range(ts)]
+        else:
+            self.acc = torch.cuda.Stream(device=device)
+            self.tail_st = [torch.cuda.Stream(device=device) for _ in range(ts)]
         self.side = self.tail_st[0]
         ev = lambda k: [torch.cuda.Event() for _ in range(k)]
         self.sort_done, self.accum_done = ev(2), ev(2)
+        self.l1_done = ev(2)
         self.tail_done = ev(self.depth)
         self.count = 0
         self._inputs = None
 
     def close(self):
-        pass
+        if self._owned:
+            torch.cuda.synchronize()
+            L = _lib.load()
+            for h in self._owned:
+                L.ozk_stream_destroy(h)
+            self._owned = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check_stream(self, main):
+        if self.tail_cus > 0 and int(main.cuda_stream) == 0:
+            raise RuntimeError("VarMsmPipeline3(tail_cus > 0) on the null stream: the confined streams are blocking "
+                               "streams and would serialise against it; submit under torch.cuda.stream(<a stream>)")
 
     def prepare(self, d_bases):
         L = _lib.load()
@@ -174,14 +215,56 @@ class VarMsmPipeline3:
         _lib.check(L.ozk_var_msm_prepare_dev(_ptr(d_bases), self.n, self.type, _ptr(out), nbytes, _stream()))
         return out
 
-    def submit(self, d_bases, d_scalars, prepared=False, last=False):
-        """last=True: the caller knows that no MSM follows this one (the end of a burst, a prover's final MSM): its
-        tail then runs with the chip to itself and takes the LATENCY shape of the window sums (fused first level +
-        wave levels: ~40 dependent additions shorter) instead of the throughput shape the overlapped tails use."""
+    def _submit_split(self, d_bases, d_scalars, prepared, last):
+        """submit() with the accumulate stage in two parts: sorted set s and accumulate scratch s are free again once
+        the REST of MSM k has run — on the tail stream, which is where accum_done[s] is recorded."""
         L = _lib.load()
         k = self.count
         s, slot = k % 2, k % self.depth
         main = torch.cuda.current_stream()
+        self._check_stream(main)
+        self._inputs = (d_bases, d_scalars)
+        if k >= 2:
+            main.wait_event(self.accum_done[s])
+        sort = L.ozk_var_msm_sort_prepared_dev if prepared else L.ozk_var_msm_sort_dev
+        _lib.check(sort(_ptr(d_bases), _ptr(d_scalars), self.n, self.type, _ptr(self.sorted[s]), self.sorted_bytes,
+                        _ptr(self.sort_ws), self.sort_ws_bytes, int(main.cuda_stream)))
+        self.sort_done[s].record(main)
+        self.acc.wait_event(self.sort_done[s])   # (ordered after rest(k - 2) through the sort's wait above)
+        if k >= self.depth:
+            self.acc.wait_event(self.tail_done[slot])
+        args = (_ptr(d_bases) if prepared else None, self.n, self.type, _ptr(self.sorted[s]), self.sorted_bytes,
+                _ptr(self.accum_ws2[s]), self.accum_ws_bytes, _ptr(self.tails[slot]), self.tail_bytes)
+        _lib.check(L.ozk_var_msm_accum_part_dev(*args, int(self.acc.cuda_stream), 1))
+        self.l1_done[s].record(self.acc)
+        T = self.tail_st[k % len(self.tail_st)]
+        R = self.rest_st or T     # (the rest on a stream of its own when the tail streams are confined to a few CUs)
+        R.wait_event(self.l1_done[s])
+        _lib.check(L.ozk_var_msm_accum_part_dev(*args, int(R.cuda_stream), 2))
+        self.accum_done[s].record(R)
+        if R is not T:
+            T.wait_event(self.accum_done[s])
+        if last:
+            _lib.check(L.ozk_var_msm_tail_mode_dev(self.n, self.type, _ptr(self.tails[slot]), self.tail_bytes,
+                                                   _ptr(self.outs[slot]), int(T.cuda_stream), None, 0))
+        else:
+            _lib.check(L.ozk_var_msm_tail_dev(self.n, self.type, _ptr(self.tails[slot]), self.tail_bytes,
+                                              _ptr(self.outs[slot]), int(T.cuda_stream)))
+        self.tail_done[slot].record(T)
+        self.count += 1
+        return k
+
+    def submit(self, d_bases, d_scalars, prepared=False, last=False):
+        """last=True: the caller knows that no MSM follows this one (the end of a burst, a prover's final MSM): its
+        tail then runs with the chip to itself and takes the LATENCY shape of the window sums (fused first level +
+        wave levels: ~40 dependent additions shorter) instead of the throughput shape the overlapped tails use."""
+        if self.split:
+            return self._submit_split(d_bases, d_scalars, prepared, last)
+        L = _lib.load()
+        k = self.count
+        s, slot = k % 2, k % self.depth
+        main = torch.cuda.current_stream()
+        self._check_stream(main)
         self._inputs = (d_bases, d_scalars)
         if k >= 2:
             main.wait_event(self.accum_done[s])        # sorted set s is free again

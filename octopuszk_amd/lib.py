@@ -41,6 +41,10 @@ _SIGS = {
     "ozk_var_msm_accum_dev": (ctypes.c_int, [i32, i32, vp, sz, vp, sz, vp, sz, vp]),
     "ozk_var_msm_sort_prepared_dev": (ctypes.c_int, [vp, vp, i32, i32, vp, sz, vp, sz, vp]),
     "ozk_var_msm_accum_prepared_dev": (ctypes.c_int, [vp, i32, i32, vp, sz, vp, sz, vp, sz, vp]),
+    "ozk_device_cu_count": (ctypes.c_int, []),
+    "ozk_stream_create_cu_range": (ctypes.c_int, [i32, i32, ctypes.POINTER(ctypes.c_void_p)]),
+    "ozk_stream_destroy": (ctypes.c_int, [vp]),
+    "ozk_var_msm_accum_part_dev": (ctypes.c_int, [vp, i32, i32, vp, sz, vp, sz, vp, sz, vp, i32]),
     "ozk_var_msm_head_workspace_bytes": (sz, [i32, i32]),
     "ozk_var_msm_tail_bytes": (sz, [i32, i32]),
     "ozk_var_msm_head_dev": (ctypes.c_int, [vp, vp, i32, i32, vp, sz, vp, sz, vp]),

@@ -214,3 +214,60 @@ def test_device_clock_timing_agrees_with_hip_events():
         assert 1000.0 < c4[2] <= c4[1] <= c4[3] < 2600.0, c4
     clock, events = (means[0] + means[2]) / 2, (means[1] + means[3]) / 2
     assert abs(clock - events) / events < 0.08, (clock, events)
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_cu_partitioned_and_split_schedules_give_the_same_bytes(split):
+    """VarMsmPipeline3(tail_cus=32): tail streams on 32 compute units, the accumulate stream on the others
+    (ozk_stream_create_cu_range); split_accum: level 1 and the rest of the accumulate stage on different streams
+    (ozk_var_msm_accum_part_dev).  Same bytes as the single-call path; the partitioned form refuses the null stream."""
+    import torch
+    from octopuszk_amd import device as dev, lib
+    L = lib.load()
+    assert L.ozk_device_cu_count() >= 64
+    n = (1 << 15) + 77
+    bases = dev.gen_g1_bases(n, seed=44)
+    inputs = [torch.from_numpy(_scalars(n, 150 + i)).cuda() for i in range(7)]
+    ws = dev.VarMsmWorkspace(n, 1)
+    serial = []
+    for d_sc in inputs:
+        out = ws.run(bases, d_sc)
+        torch.cuda.synchronize()
+        serial.append(bytes(out.cpu().numpy()))
+    pipe = dev.VarMsmPipeline3(n, 1, depth=4, tail_streams=2, tail_cus=32, split_accum=split)
+    with pytest.raises(RuntimeError, match="null stream"):
+        pipe.submit(bases, inputs[0])
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        ts = [pipe.submit(bases, d_sc, last=(i == 6)) for i, d_sc in enumerate(inputs[:4])]
+        torch.cuda.synchronize()
+        got = [bytes(pipe.outs[t % pipe.depth].cpu().numpy()) for t in ts]
+        ts = [pipe.submit(bases, d_sc) for d_sc in inputs[4:]]
+        torch.cuda.synchronize()
+        got += [bytes(pipe.outs[t % pipe.depth].cpu().numpy()) for t in ts]
+    assert got == serial
+    pipe.close()
+    with pytest.raises(ValueError):
+        dev.VarMsmPipeline3(n, 1, tail_cus=100000)
+
+
+def test_split_accumulate_stage_without_partition():
+    import torch
+    from octopuszk_amd import device as dev
+    n = 5000
+    bases = dev.gen_g1_bases(n, seed=45)
+    inputs = [torch.from_numpy(_scalars(n, 170 + i)).cuda() for i in range(6)]
+    ws = dev.VarMsmWorkspace(n, 1)
+    serial = []
+    for d_sc in inputs:
+        out = ws.run(bases, d_sc)
+        torch.cuda.synchronize()
+        serial.append(bytes(out.cpu().numpy()))
+    pipe = dev.VarMsmPipeline3(n, 1, depth=4, split_accum=True)
+    b = pipe.prepare(bases)
+    got = []
+    for half in (inputs[:3], inputs[3:]):
+        ts = [pipe.submit(b, d_sc, prepared=True) for d_sc in half]
+        torch.cuda.synchronize()
+        got += [bytes(pipe.outs[t % pipe.depth].cpu().numpy()) for t in ts]
+    assert got == serial

@@ -23,15 +23,21 @@ ap.add_argument("--fit", action="store_true", help="time 10/20/40/100/200 MSMs (
 ap.add_argument("--sort-prio", type=int, default=None, help="run the sort stage on a new stream of this priority (-1 = high)")
 ap.add_argument("--acc-prio", type=int, default=None)
 ap.add_argument("--tail-prio", type=int, default=None)
+ap.add_argument("--tail-cus", type=int, default=0, help="tail streams created with a CU mask of this many bits (hipExtStreamCreateWithCUMask)")
+ap.add_argument("--acc-mask", default="full", help="full | comp (the accumulate stream gets the complement of the tail's mask)")
+ap.add_argument("--sort-mask", default="full", help="full | tail (sort stage on a stream with the tail's mask) | comp")
+ap.add_argument("--class-tail-cus", type=int, default=0, help="VarMsmPipeline3(tail_cus=N): the shipped form of --tail-cus N --acc-mask comp (runs on a side stream)")
+ap.add_argument("--rest-stream", default="tail", help="with OZK_P3_SPLIT_ACCUM=1: tail | own (an unmasked stream) | comp (a stream with the accumulate mask)")
+ap.add_argument("--mask-layout", default="low", help="low: bits [0, N) | high: bits [256 - N, 256)")
 a = ap.parse_args()
 L = ozk.load()
 n = 1 << a.logn
 bases = dev.gen_g1_bases(n, seed=2)
 sc = np.random.default_rng(10).integers(0, 256, size=(n, 32), dtype=np.uint8); sc[:, 31] &= 0x1F
 d_sc = torch.from_numpy(sc.reshape(-1)).cuda()
-pipe = dev.VarMsmPipeline3(n, 1, depth=a.depth, tail_streams=a.tail_streams) if a.sched == "p3" else dev.VarMsmPipeline(n, 1, depth=2)
+pipe = dev.VarMsmPipeline3(n, 1, depth=a.depth, tail_streams=a.tail_streams, tail_cus=a.class_tail_cus) if a.sched == "p3" else dev.VarMsmPipeline(n, 1, depth=2)
 b = pipe.prepare(bases) if a.prepared else bases
-st = torch.cuda.Stream() if a.own_sort_stream else torch.cuda.current_stream()
+st = torch.cuda.Stream() if (a.own_sort_stream or a.class_tail_cus) else torch.cuda.current_stream()
 if a.sort_prio is not None:
     st = torch.cuda.Stream(priority=a.sort_prio)
 if a.acc_prio is not None and a.sched == "p3":
@@ -39,6 +45,24 @@ if a.acc_prio is not None and a.sched == "p3":
 if a.tail_prio is not None and a.sched == "p3":
     pipe.tail_st = [torch.cuda.Stream(priority=a.tail_prio) for _ in pipe.tail_st]
     pipe.side = pipe.tail_st[0]
+if a.tail_cus and a.sched == "p3":
+    hip = ctypes.CDLL("libamdhip64.so")
+    def masked(bits):
+        words = [0] * 8
+        for i in bits: words[i // 32] |= 1 << (i % 32)
+        h = ctypes.c_void_p(); arr = (ctypes.c_uint32 * 8)(*words)
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), 8, arr)
+        assert rc == 0, rc
+        return torch.cuda.ExternalStream(h.value)
+    tb = list(range(a.tail_cus)) if a.mask_layout == "low" else list(range(256 - a.tail_cus, 256))
+    cb = [i for i in range(256) if i not in tb]
+    pipe.tail_st = [masked(tb) for _ in pipe.tail_st]
+    pipe.side = pipe.tail_st[0]
+    if a.acc_mask == "comp": pipe.acc = masked(cb)
+    if a.rest_stream == "comp": pipe.rest_st = masked(cb)
+    if a.sort_mask == "tail": st = masked(tb)
+    elif a.sort_mask == "comp": st = masked(cb)
+if a.rest_stream == "own" and a.sched == "p3": pipe.rest_st = torch.cuda.Stream()
 with torch.cuda.stream(st):
     for _ in range(6): t = pipe.submit(b, d_sc, prepared=a.prepared)
     torch.cuda.synchronize()
@@ -93,7 +117,7 @@ with torch.cuda.stream(st):
     t0 = time.perf_counter()
     for _ in range(a.reps): t = pipe.submit(b, d_sc, prepared=a.prepared)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-msg = "%s depth=%d ts=%d prof=%d: %.1f Mscalar-mul/s (%.3f ms per MSM)" % (a.sched, a.depth, a.tail_streams, a.prof, a.reps * n / dt / 1e6, dt / a.reps * 1e3)
+msg = ("class tail_cus=%d " % a.class_tail_cus if a.class_tail_cus else "") + ("tail_cus=%d acc=%s sort=%s %s " % (a.tail_cus, a.acc_mask, a.sort_mask, a.mask_layout) if a.tail_cus else "") + "%s depth=%d ts=%d prof=%d: %.1f Mscalar-mul/s (%.3f ms per MSM)" % (a.sched, a.depth, a.tail_streams, a.prof, a.reps * n / dt / 1e6, dt / a.reps * 1e3)
 if a.prof:
     s4 = (ctypes.c_double * 4)(); k = ctypes.c_int()
     ozk.check(L.ozk_prof_dominant_kernel_stats(s4, ctypes.byref(k)))
