@@ -36,6 +36,18 @@ def to_device(a):
     return t.pin_memory().cuda()
 
 
+def from_device(t):
+    """device -> numpy through PINNED memory, for the same reason (round 4: t.cpu() into a large pageable temporary
+    registers that range just as an upload does — the collection of a280974 showed the alternating 6 / 17-40 ms calls
+    again for `--only=double --only=fixed_batch_msm_host`, whose set-up downloads the generated bases that way)"""
+    if "--pageable-uploads" in sys.argv:
+        return t.cpu().numpy()
+    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    h.copy_(t)
+    torch.cuda.synchronize()
+    return np.array(h.numpy(), copy=True)
+
+
 def vp(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
@@ -53,6 +65,22 @@ def fresh(a):
 
 ONLY = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--only=")]
 ALL_STATS = "--all-stats" in sys.argv
+REPS = [int(a.split("=", 1)[1]) for a in sys.argv[1:] if a.startswith("--reps=")]   # --reps=N: N calls of every entry
+
+
+def throttled_us():
+    """microseconds this container's cgroup has spent THROTTLED by its CPU quota so far (cgroup v2 cpu.stat
+    throttled_usec, v1 throttled_time in ns), or None"""
+    for path, key, div in (("/sys/fs/cgroup/cpu.stat", "throttled_usec", 1), ("/sys/fs/cgroup/cpu/cpu.stat", "throttled_time", 1000),
+                           ("/sys/fs/cgroup/cpu,cpuacct/cpu.stat", "throttled_time", 1000)):
+        try:
+            for line in open(path):
+                k, v = line.split()
+                if k == key:
+                    return int(v) // div
+        except (OSError, ValueError):
+            pass
+    return None
 
 
 def run(name, fn, make_inputs, reps, moved_mib, dev_ms=None):
@@ -60,14 +88,20 @@ def run(name, fn, make_inputs, reps, moved_mib, dev_ms=None):
         return
     import resource
     times, stats, faults = [], [], []
+    if REPS:
+        reps = REPS[0]
     for _ in range(reps + 1):
         args = make_inputs()
         ru0 = resource.getrusage(resource.RUSAGE_SELF)
+        th0 = throttled_us()
         t0 = time.perf_counter()
         fn(*args)
         times.append((time.perf_counter() - t0) * 1e3)
+        th1 = throttled_us()
         ru1 = resource.getrusage(resource.RUSAGE_SELF)
-        faults.append((ru1.ru_minflt - ru0.ru_minflt, ru1.ru_nvcsw - ru0.ru_nvcsw, ru1.ru_nivcsw - ru0.ru_nivcsw))
+        faults.append((ru1.ru_minflt - ru0.ru_minflt, ru1.ru_nvcsw - ru0.ru_nvcsw, ru1.ru_nivcsw - ru0.ru_nivcsw,
+                       -1.0 if th0 is None or th1 is None else (th1 - th0) / 1e3,
+                       (ru1.ru_utime + ru1.ru_stime - ru0.ru_utime - ru0.ru_stime) * 1e3))
         st = (ctypes.c_double * 10)()
         L.ozk_host_call_stats(st)
         stats.append(list(st))
@@ -75,7 +109,7 @@ def run(name, fn, make_inputs, reps, moved_mib, dev_ms=None):
         f = ("acquire", "reserve", "stage_wait", "memcpy_in", "memcpy_out", "enqueue", "sync")
         for i, (t, st_, fl) in enumerate(zip(times, stats, faults)):
             print("    call %d: %6.2f ms (library %6.2f)  " % (i, t, st_[9]) + "  ".join("%s %.2f" % (n_, v) for n_, v in zip(f, st_))
-                  + "  | minor faults %d  ctx switches %d + %d" % fl, flush=True)
+                  + "  | minor faults %d  ctx switches %d + %d  cgroup throttled %.1f ms  process CPU %.1f ms" % fl, flush=True)
     warm = sorted(times[1:])
     extra = "" if dev_ms is None else "  | device-resident %.2f ms" % dev_ms
     print("%-46s first %8.2f ms | min %7.2f  median %7.2f ms | %5.0f MiB over PCIe%s   all: %s"
@@ -92,8 +126,7 @@ def main():
     logn = int(pos[0]) if pos else 20
     n = 1 << logn
     print("device:", torch.cuda.get_device_name(0), " n = 2^%d" % logn, flush=True)
-    g1 = bytes(dev.gen_g1_bases(n, seed=2).cpu().numpy())
-    g1 = np.frombuffer(g1, dtype=np.uint8)
+    g1 = from_device(dev.gen_g1_bases(n, seed=2))
     sc = scalars(n, 1)
     out = np.zeros(576, dtype=np.uint8)
     # device-resident reference
@@ -136,7 +169,7 @@ def main():
     ozk.check(L.ozk_fixed_batch_msm_compact_dev(16, 16, m, int(base2.data_ptr()), int(d_ks.data_ptr()),
                                                 2, int(g2d.data_ptr()), int(wsf.data_ptr()), wsb, st))
     torch.cuda.synchronize()
-    g2 = g2d.cpu().numpy()
+    g2 = from_device(g2d)
     del wsf, g2d
 
     def dbl(b1, b2, s):
