@@ -271,3 +271,27 @@ def test_split_accumulate_stage_without_partition():
         torch.cuda.synchronize()
         got += [bytes(pipe.outs[t % pipe.depth].cpu().numpy()) for t in ts]
     assert got == serial
+
+
+def test_split_accumulate_stage_g2():
+    """the two-part accumulate stage over G2 (level 1 with its accumulators in LDS) against the single-call path"""
+    import numpy as np
+    import torch
+    from octopuszk_amd import device as dev
+    rng = random.Random(9)
+    n, G = 700, o.G2
+    pts = [G.to_affine(G.mul(G.one, rng.randrange(1, 1 << 64))) for _ in range(32)]
+    d_bases = torch.from_numpy(np.frombuffer(b"".join(o.g2_to_wire(pts[i % 32]) for i in range(n)), dtype=np.uint8).copy()).cuda()
+    inputs = [torch.from_numpy(_scalars(n, 190 + i)).cuda() for i in range(5)]
+    ws = dev.VarMsmWorkspace(n, 2)
+    serial = []
+    for d_sc in inputs:
+        out = ws.run(d_bases, d_sc)
+        torch.cuda.synchronize()
+        serial.append(bytes(out.cpu().numpy()))
+    pipe = dev.VarMsmPipeline3(n, 2, depth=4, split_accum=True)
+    got = []
+    for d_sc in inputs:
+        t = pipe.submit(d_bases, d_sc)
+        got.append(bytes(pipe.result(t).cpu().numpy()))
+    assert got == serial
